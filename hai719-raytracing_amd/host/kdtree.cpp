@@ -1,0 +1,235 @@
+#include "kdtree.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+
+namespace hrt_host {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct TriRef {
+    uint32_t id;
+    Box b;  // triangle bounds clipped to the cell that currently owns the ref
+};
+
+struct BuildNode {
+    int axis = -1;  // -1: leaf
+    float split = 0.f;
+    int left = -1, right = -1;
+    Box cell;
+    std::vector<uint32_t> tris;  // leaf only
+    int rope[6] = {-1, -1, -1, -1, -1, -1};
+    uint32_t unit = 0;  // position in the flattened array
+};
+
+struct Builder {
+    const KDBuildParams &prm;
+    uint32_t max_depth;
+    std::vector<BuildNode> nodes;
+    uint32_t depth_reached = 0;
+
+    explicit Builder(const KDBuildParams &p, uint32_t nt) : prm(p) {
+        max_depth = p.max_depth ? p.max_depth : (uint32_t)(8.0 + 1.3 * std::log2((double)std::max(nt, 1u)));
+    }
+
+    int make_leaf(const Box &cell, const std::vector<TriRef> &refs) {
+        BuildNode n;
+        n.cell = cell;
+        n.tris.reserve(refs.size());
+        for (const TriRef &r : refs) n.tris.push_back(r.id);
+        std::sort(n.tris.begin(), n.tris.end());
+        nodes.push_back(std::move(n));
+        return (int)nodes.size() - 1;
+    }
+
+    // Surface-area heuristic over all triangle-bound planes strictly inside the cell.
+    bool best_split(const Box &cell, const std::vector<TriRef> &refs, int &axis_out, float &pos_out) {
+        const size_t n = refs.size();
+        const float inv_area = 1.f / std::max(cell.area(), 1e-30f);
+        float best = prm.cost_intersect * (float)n;  // cost of not splitting
+        bool found = false;
+        std::vector<float> mins(n), maxs(n);
+        for (int a = 0; a < 3; ++a) {
+            if (!(cell.hi[a] > cell.lo[a])) continue;
+            for (size_t i = 0; i < n; ++i) { mins[i] = refs[i].b.lo[a]; maxs[i] = refs[i].b.hi[a]; }
+            std::sort(mins.begin(), mins.end());
+            std::sort(maxs.begin(), maxs.end());
+            auto consider = [&](float p) {
+                if (!(p > cell.lo[a]) || !(p < cell.hi[a])) return;
+                size_t nl = std::lower_bound(mins.begin(), mins.end(), p) - mins.begin();  // min < p
+                size_t nr = n - (std::upper_bound(maxs.begin(), maxs.end(), p) - maxs.begin());  // max > p
+                Box L = cell, R = cell;
+                L.hi[a] = p;
+                R.lo[a] = p;
+                float c = prm.cost_traverse +
+                          prm.cost_intersect * inv_area * (L.area() * (float)nl + R.area() * (float)nr);
+                if (nl == 0 || nr == 0) c *= prm.empty_bonus;
+                if (c < best) { best = c; axis_out = a; pos_out = p; found = true; }
+            };
+            float last = NAN;
+            for (size_t i = 0; i < n; ++i) if (mins[i] != last) { last = mins[i]; consider(last); }
+            last = NAN;
+            for (size_t i = 0; i < n; ++i) if (maxs[i] != last) { last = maxs[i]; consider(last); }
+        }
+        return found;
+    }
+
+    int build(const Box &cell, std::vector<TriRef> &refs, uint32_t depth) {
+        depth_reached = std::max(depth_reached, depth);
+        int axis = -1;
+        float pos = 0.f;
+        if (refs.size() <= prm.leaf_max || depth >= max_depth || !best_split(cell, refs, axis, pos))
+            return make_leaf(cell, refs);
+        std::vector<TriRef> lrefs, rrefs;
+        for (const TriRef &r : refs) {
+            const bool to_left = (r.b.lo[axis] < pos) || (r.b.hi[axis] <= pos);
+            const bool to_right = (r.b.hi[axis] > pos) || (r.b.lo[axis] >= pos);
+            if (to_left) { TriRef c = r; c.b.hi[axis] = std::min(c.b.hi[axis], pos); lrefs.push_back(c); }
+            if (to_right) { TriRef c = r; c.b.lo[axis] = std::max(c.b.lo[axis], pos); rrefs.push_back(c); }
+        }
+        std::vector<TriRef>().swap(refs);
+        Box lc = cell, rc = cell;
+        lc.hi[axis] = pos;
+        rc.lo[axis] = pos;
+        int self = (int)nodes.size();
+        nodes.emplace_back();
+        nodes[self].axis = axis;
+        nodes[self].split = pos;
+        nodes[self].cell = cell;
+        int l = build(lc, lrefs, depth + 1);
+        int r = build(rc, rrefs, depth + 1);
+        nodes[self].left = l;
+        nodes[self].right = r;
+        return self;
+    }
+
+    // Push a rope down to the deepest node whose cell still covers the whole face `f` of `box`.
+    int tighten(int r, int f, const Box &box) const {
+        while (r >= 0 && nodes[r].axis >= 0) {
+            const BuildNode &n = nodes[r];
+            const int fa = f >> 1;
+            if (n.axis == fa) r = (f & 1) ? n.left : n.right;
+            else if (n.split <= box.lo[n.axis]) r = n.right;
+            else if (n.split >= box.hi[n.axis]) r = n.left;
+            else break;
+        }
+        return r;
+    }
+
+    void assign_ropes(int ni, const int in[6]) {
+        BuildNode &n = nodes[ni];
+        int rp[6];
+        for (int f = 0; f < 6; ++f) rp[f] = tighten(in[f], f, n.cell);
+        if (n.axis < 0) {
+            std::memcpy(n.rope, rp, sizeof(rp));
+            return;
+        }
+        int lr[6], rr[6];
+        std::memcpy(lr, rp, sizeof(rp));
+        std::memcpy(rr, rp, sizeof(rp));
+        lr[2 * n.axis + 1] = n.right;
+        rr[2 * n.axis] = n.left;
+        const int l = n.left, r = n.right;  // n may dangle after recursion only if nodes grew; it does not here
+        assign_ropes(l, lr);
+        assign_ropes(r, rr);
+    }
+};
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+}  // namespace
+
+FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t *indices,
+                             uint32_t nt, const KDBuildParams &params) {
+    FlatKDTree out;
+    if (nt == 0) return out;
+    (void)nv;
+    std::vector<TriRef> refs(nt);
+    Box root;
+    for (int a = 0; a < 3; ++a) { root.lo[a] = INFINITY; root.hi[a] = -INFINITY; }
+    for (uint32_t t = 0; t < nt; ++t) {
+        TriRef &r = refs[t];
+        r.id = t;
+        for (int a = 0; a < 3; ++a) { r.b.lo[a] = INFINITY; r.b.hi[a] = -INFINITY; }
+        for (int k = 0; k < 3; ++k) {
+            const float *p = positions + 3 * (size_t)indices[3 * (size_t)t + k];
+            for (int a = 0; a < 3; ++a) {
+                r.b.lo[a] = std::min(r.b.lo[a], p[a]);
+                r.b.hi[a] = std::max(r.b.hi[a], p[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            root.lo[a] = std::min(root.lo[a], r.b.lo[a]);
+            root.hi[a] = std::max(root.hi[a], r.b.hi[a]);
+        }
+    }
+    // Pad the root cell so that hits on the hull are strictly inside it.
+    for (int a = 0; a < 3; ++a) {
+        float pad = 1e-4f * std::max(1.f, std::max(std::fabs(root.lo[a]), std::fabs(root.hi[a])));
+        root.lo[a] -= pad;
+        root.hi[a] += pad;
+    }
+
+    Builder b(params, nt);
+    const int root_node = b.build(root, refs, 0);
+    const int nil[6] = {-1, -1, -1, -1, -1, -1};
+    b.assign_ropes(root_node, nil);
+
+    // Breadth-first numbering in 16-byte units: inner = 1 unit, leaf = 4 units.
+    std::vector<int> order;
+    order.reserve(b.nodes.size());
+    std::deque<int> queue{root_node};
+    uint32_t next_unit = 0;
+    while (!queue.empty()) {
+        int ni = queue.front();
+        queue.pop_front();
+        BuildNode &n = b.nodes[ni];
+        n.unit = next_unit;
+        next_unit += (n.axis < 0) ? 4u : 1u;
+        order.push_back(ni);
+        if (n.axis >= 0) { queue.push_back(n.left); queue.push_back(n.right); }
+    }
+    auto ref_of = [&](int ni) -> uint32_t {
+        if (ni < 0) return HRT_KD_NIL;
+        const BuildNode &n = b.nodes[ni];
+        return n.unit | (n.axis < 0 ? HRT_KD_LEAF : 0u);
+    };
+    out.units.assign(next_unit, hrt_kdunit{{0, 0, 0, 0}});
+    for (int ni : order) {
+        const BuildNode &n = b.nodes[ni];
+        hrt_kdunit *u = &out.units[n.unit];
+        if (n.axis >= 0) {
+            u[0].w[0] = f2u(n.split);
+            u[0].w[1] = (uint32_t)n.axis;
+            u[0].w[2] = ref_of(n.left);
+            u[0].w[3] = ref_of(n.right);
+            ++out.n_inner;
+        } else {
+            u[0].w[0] = f2u(n.cell.lo[0]); u[0].w[1] = f2u(n.cell.lo[1]); u[0].w[2] = f2u(n.cell.lo[2]);
+            u[0].w[3] = (uint32_t)out.leaf_tris.size();
+            u[1].w[0] = f2u(n.cell.hi[0]); u[1].w[1] = f2u(n.cell.hi[1]); u[1].w[2] = f2u(n.cell.hi[2]);
+            u[1].w[3] = (uint32_t)n.tris.size();
+            for (int f = 0; f < 4; ++f) u[2].w[f] = ref_of(n.rope[f]);
+            u[3].w[0] = ref_of(n.rope[4]);
+            u[3].w[1] = ref_of(n.rope[5]);
+            out.leaf_tris.insert(out.leaf_tris.end(), n.tris.begin(), n.tris.end());
+            ++out.n_leaves;
+            if (n.tris.empty()) ++out.n_empty_leaves;
+        }
+    }
+    out.root = ref_of(root_node);
+    for (int a = 0; a < 3; ++a) { out.root_lo[a] = root.lo[a]; out.root_hi[a] = root.hi[a]; }
+    out.depth = b.depth_reached;
+    return out;
+}
+
+}  // namespace hrt_host

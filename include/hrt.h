@@ -1,0 +1,214 @@
+/*
+ * hrt.h -- C ABI of the MI355X ray-trace path (libhrt.so).
+ *
+ * This is the drop-in boundary for the reference's 'r'-triggered render:
+ *   key 'r'                         /root/reference/main.cpp:321-325
+ *   void ray_trace_from_camera()    /root/reference/main.cpp:200-263
+ *     -> trace_line()               /root/reference/main.cpp:183-198
+ *        -> Scene::rayTrace()       /root/reference/src/Scene.h:345-350
+ * The reference has no FFI of its own; a maintainer replaces
+ * the body of ray_trace_from_camera() with: flatten scene -> hrt_scene_create
+ * -> hrt_render -> PPM dump.
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No torch / HIP types.
+ * All functions return 0 on success or a negative hrt_status; they never
+ * throw.  hrt_last_error() gives the text of the last failure on the calling
+ * thread.  Calls are blocking unless a stream is given.
+ */
+#ifndef HRT_H
+#define HRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- compile-time constants of the path (reference src/Constants.h) ---- */
+#define HRT_MAXBOUNCES 6             /* Constants.h:11  MAXBOUNCES            */
+#define HRT_NB_ECH 10                /* Constants.h:12  shadow rays per light  */
+#define HRT_EPSILON 0.00001          /* Constants.h:18  (a double literal)     */
+#define HRT_TRIANGLE_SCALING 1.000001f /* Mesh.h:23                             */
+
+typedef enum hrt_status {
+    HRT_OK = 0,
+    HRT_ERR_INVALID = -1,   /* bad argument / inconsistent scene description   */
+    HRT_ERR_DEVICE = -2,    /* HIP runtime failure (no GPU, OOM, launch error) */
+    HRT_ERR_STATE = -3,     /* library not initialised / scene destroyed       */
+    HRT_ERR_IO = -4         /* file could not be read / written                */
+} hrt_status;
+
+/* Material.h:11-21 */
+enum { HRT_MAT_DIFFUSE = 0, HRT_MAT_GLASS = 1, HRT_MAT_MIRROR = 2 };
+enum { HRT_TEX_NONE = 0, HRT_TEX_CHECKER = 1, HRT_TEX_IMAGE = 2 };
+/* Mesh.h:64-68 */
+enum { HRT_COLOR_VERTEX = 0, HRT_COLOR_FACE = 1, HRT_COLOR_NONE = 2 };
+
+/* The fields of reference `struct Material` (Material.h:23-50) that the hot
+ * path reads.  ambient/specular/shininess are never read by the integrator
+ * (Scene.h:317 is commented out) and are not carried. */
+typedef struct hrt_material {
+    float albedo[3];          /* diffuse_material                              */
+    float transparency;
+    float index_medium;
+    int32_t type;             /* HRT_MAT_*                                      */
+    int32_t texture_type;     /* HRT_TEX_*                                      */
+    float checker1[3];
+    float checker2[3];
+    float tex_scale_x, tex_scale_y;
+    int32_t emissive;         /* 0/1; undefined in the reference => 0 (N10)     */
+    float light_color[3];
+    float light_intensity;
+    int32_t image;            /* index into images[], -1 = none                 */
+    int32_t normal_map;       /* index into images[], -1 = no normal map        */
+    float motion[3];          /* motion_blur_translation                        */
+} hrt_material;
+
+/* ppmLoader::ImageRGB (imageLoader.h:18-22): tightly packed RGB8, row-major. */
+typedef struct hrt_image {
+    int32_t w, h;
+    const uint8_t *rgb;
+} hrt_image;
+
+/* Sphere.h:45-47 */
+typedef struct hrt_sphere {
+    float center[3];
+    float radius;
+    int32_t material;
+} hrt_sphere;
+
+/* Square: intersect() reads vertices[0],[1],[3] (Square.h:68-70); the normal
+ * map frame is m_right_vector / m_up_vector as left by setQuad (Square.h:35-45,
+ * Scene.h:284), which later transforms do NOT update. */
+typedef struct hrt_quad {
+    float v0[3], v1[3], v3[3];
+    float tangent[3], bitangent[3];
+    int32_t material;
+} hrt_quad;
+
+/* Scene.h:28-41; only pos/radius/material are read (Scene.h:306-333). */
+typedef struct hrt_light {
+    float pos[3];
+    float radius;
+    float color[3];
+} hrt_light;
+
+/* Flattened KD-tree with ropes, in 16-byte units ("nodelets").
+ *   ref = unit index | HRT_KD_LEAF (leaf) ; HRT_KD_NIL = no neighbour.
+ *   inner nodelet (1 unit):  { f32 split, u32 axis, u32 left_ref, u32 right_ref }
+ *   leaf  nodelet (4 units): { bmin.xyz, u32 tri_first | bmax.xyz, u32 tri_count |
+ *                              rope[-x,+x,-y,+y] | rope[-z,+z], 0, 0 }
+ * tri_first/tri_count index leaf_tris[] (triangle ids of the mesh).
+ * Units are laid out breadth-first so a prefix of the array is the top of the
+ * tree (that prefix is what the kernel stages into LDS). */
+#define HRT_KD_LEAF 0x80000000u
+#define HRT_KD_NIL 0xFFFFFFFFu
+typedef struct hrt_kdunit {
+    uint32_t w[4];
+} hrt_kdunit;
+
+typedef struct hrt_mesh {
+    uint32_t n_vertices, n_triangles;
+    const float *positions;      /* 3*n_vertices, world space, NOT yet scaled by
+                                    HRT_TRIANGLE_SCALING (KDTree.cpp:38-40)      */
+    const uint32_t *indices;     /* 3*n_triangles                               */
+    int32_t color_type;          /* HRT_COLOR_*                                 */
+    const float *vert_colors;    /* 3*n_vertices or NULL                        */
+    const float *face_colors;    /* 3*n_triangles or NULL                       */
+    float aabb_min[3], aabb_max[3]; /* Mesh::computeAABB (Mesh.h:143-157)       */
+    int32_t material;
+    /* flattened KD-tree (built by the host layer, hrt_host.h) */
+    uint32_t kd_root;            /* ref of the root                             */
+    float kd_min[3], kd_max[3];  /* root cell of the tree (scaled-triangle hull, padded) */
+    uint32_t n_kd_units;
+    const hrt_kdunit *kd_units;
+    uint32_t n_leaf_tris;
+    const uint32_t *leaf_tris;
+} hrt_mesh;
+
+typedef struct hrt_scene_desc {
+    uint32_t n_materials;  const hrt_material *materials;
+    uint32_t n_spheres;    const hrt_sphere *spheres;
+    uint32_t n_quads;      const hrt_quad *quads;
+    uint32_t n_meshes;     const hrt_mesh *meshes;
+    uint32_t n_lights;     const hrt_light *lights;
+    uint32_t n_images;     const hrt_image *images;
+    int32_t dark_sky;      /* Scene.h:65                                        */
+    int32_t skybox_image;  /* index into images[] or -1 (Scene.h:149-161)       */
+} hrt_scene_desc;
+
+/* Replaces the GL read-back of matrixUtilities.h:33-74: eye + orthonormal
+ * basis + the gluPerspective parameters of Camera.cpp:24-28,41-50.
+ * Reference default: eye (0,0,6.1), right +X, up +Y, forward -Z, fovy 45,
+ * znear 4.1, zfar 1e4, aspect = w/h. */
+typedef struct hrt_camera {
+    float eye[3];
+    float right[3], up[3], forward[3];
+    float fovy_deg;
+    float aspect;
+    float znear, zfar;
+} hrt_camera;
+
+/* Image-tile partition of one frame across ranks (one process per GPU).
+ * Tiles are HRT_TILE x HRT_TILE pixels, numbered row-major; rank r renders
+ * tiles r, r+world, r+2*world, ... and writes them densely, tile-major, into
+ * its own buffer (hrt_tiles_owned() tiles of HRT_TILE*HRT_TILE*3 floats). */
+#define HRT_TILE 8
+
+enum {
+    HRT_FLAG_GAMMA = 1u,       /* apply pow(c,1/2.2) (main.cpp:196)             */
+    HRT_FLAG_NO_LDS_TREE = 2u  /* debug: fetch every nodelet from global memory */
+};
+
+typedef struct hrt_stats {
+    double kernel_ms;          /* HIP-event time of the trace kernel(s)         */
+    double total_ms;           /* wall time of the call                         */
+    uint64_t samples;          /* pixels * spp rendered by this call            */
+    uint32_t vgprs, sgprs, lds_bytes, waves_launched;
+} hrt_stats;
+
+typedef struct hrt_scene hrt_scene;   /* opaque: device-resident SoA scene */
+
+int hrt_init(int device_ordinal);
+void hrt_shutdown(void);
+const char *hrt_last_error(void);
+int hrt_device_count(void);
+
+/* Upload: repack the description into device SoA arrays.  The description
+ * (and everything it points to) may be freed after the call returns. */
+int hrt_scene_create(const hrt_scene_desc *desc, hrt_scene **out);
+void hrt_scene_destroy(hrt_scene *scene);
+
+/* Whole frame on the current device into a HOST buffer out_rgb[h*w*3]
+ * (row-major x + y*w, as main.cpp:193).  Value = mean over spp of
+ * Scene::rayTrace, gamma-corrected when HRT_FLAG_GAMMA. */
+int hrt_render(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
+               uint32_t spp, uint64_t seed, uint32_t flags, float *out_rgb,
+               hrt_stats *stats /* may be NULL */);
+
+/* Multi-GPU building blocks (device pointers; `stream` is a hipStream_t cast
+ * to void*, NULL = the default stream).  Asynchronous w.r.t. the host. */
+uint32_t hrt_tiles_total(uint32_t w, uint32_t h);
+uint32_t hrt_tiles_owned(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);
+int hrt_render_tiles(hrt_scene *scene, const hrt_camera *cam, uint32_t w,
+                     uint32_t h, uint32_t spp, uint64_t seed, uint32_t flags,
+                     uint32_t rank, uint32_t world,
+                     float *d_tiles /* device, hrt_tiles_owned()*HRT_TILE^2*3 */,
+                     void *stream);
+/* Rank 0 after the gather: d_gathered holds world blocks of
+ * tiles_per_rank_padded tiles (rank-major); writes the row-major frame. */
+int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded,
+                       uint32_t w, uint32_t h, uint32_t world,
+                       float *d_frame /* device, h*w*3 */, void *stream);
+/* Timing of the last hrt_render_tiles on this scene (after a sync). */
+int hrt_last_kernel_ms(hrt_scene *scene, double *ms);
+int hrt_kernel_info(hrt_stats *out);
+
+/* Output stage of main.cpp:252-262: P3 ASCII with (int)(255*min(1,c)). */
+int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRT_H */

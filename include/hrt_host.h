@@ -1,0 +1,68 @@
+/*
+ * hrt_host.h -- C ABI of the host scene layer (libhrt_host.so, plain C++, no GPU).
+ *
+ * The host layer is the caller side of the trace path: it owns Scene / Mesh /
+ * Material objects with the reference's interface (hai719-raytracing_amd/host/),
+ * builds the flattened KD-trees and produces the hrt_scene_desc that
+ * hrt_scene_create() (hrt.h) uploads.  C++ callers use the classes directly;
+ * this C ABI exists so that tests, bench.py and other languages can reach the
+ * same code.  Reference lines: Scene.h:57-188, 352-356, 421-619, 829-924,
+ * 1329-1882; Mesh.cpp:9-117; KDTree.cpp:87-151; imageLoader.cpp:21-103.
+ */
+#ifndef HRT_HOST_H
+#define HRT_HOST_H
+
+#include "hrt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hrt_host_scene hrt_host_scene;
+
+const char *hrt_host_last_error(void);
+
+/* asset_root = directory that holds img/ and mesh/ (the reference reads them
+ * relative to the cwd). */
+int hrt_host_scene_new(const char *asset_root, hrt_host_scene **out);
+void hrt_host_scene_free(hrt_host_scene *s);
+
+/* name: "cornell_box" (cfg 1), "cornell_mesh" (cfg 2), "random_spheres"
+ * (cfg 3), "mesh_in_box" (cfg 4), "backrooms_pool" (cfg 5). */
+int hrt_host_scene_setup(hrt_host_scene *s, const char *name, float aspect_ratio, uint64_t seed);
+
+/* Programmatic construction (used by the parity tests for synthetic scenes).
+ * `material->image` / `normal_map` index the textures / normal maps added
+ * through the two calls below, in order. */
+int hrt_host_scene_clear(hrt_host_scene *s);
+int hrt_host_scene_add_texture(hrt_host_scene *s, int32_t w, int32_t h, const uint8_t *rgb);
+int hrt_host_scene_add_normal_map(hrt_host_scene *s, int32_t w, int32_t h, const uint8_t *rgb);
+int hrt_host_scene_add_sphere(hrt_host_scene *s, const float center[3], float radius,
+                              const hrt_material *material);
+/* Square::setQuad(bottomLeft, rightVector, upVector, width, height) */
+int hrt_host_scene_add_quad(hrt_host_scene *s, const float bottom_left[3], const float right[3],
+                            const float up[3], float width, float height,
+                            const hrt_material *material);
+int hrt_host_scene_add_mesh(hrt_host_scene *s, const float *positions, uint32_t n_vertices,
+                            const uint32_t *indices, uint32_t n_triangles,
+                            const float *face_colors /* 3*n_triangles or NULL */,
+                            const hrt_material *material);
+int hrt_host_scene_add_mesh_off(hrt_host_scene *s, const char *off_path_relative_to_root,
+                                const hrt_material *material);
+int hrt_host_scene_add_light(hrt_host_scene *s, const float pos[3], float radius, const float color[3]);
+int hrt_host_scene_set_sky(hrt_host_scene *s, int32_t dark_sky);
+/* leaf_max / max_depth of the SAH builder (0 keeps the default). */
+int hrt_host_scene_set_kd_params(hrt_host_scene *s, uint32_t leaf_max, uint32_t max_depth);
+
+/* Builds the KD-trees and the flat description.  The pointer stays valid until
+ * the next flatten / free of this scene. */
+int hrt_host_scene_flatten(hrt_host_scene *s, const hrt_scene_desc **out);
+/* out[0..5] = inner nodes, leaves, empty leaves, depth, leaf triangle refs, 16-byte units */
+int hrt_host_scene_kd_stats(hrt_host_scene *s, uint32_t mesh_index, uint32_t out[6]);
+
+void hrt_host_default_camera(float aspect_ratio, hrt_camera *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRT_HOST_H */
