@@ -33,6 +33,10 @@ class HrtError(RuntimeError):
     pass
 
 
+class SceneDescPtr(C.c_void_p):
+    """``const hrt_scene_desc*`` that keeps the HostScene owning the memory alive."""
+
+
 # ----------------------------------------------------------------- PODs (hrt.h)
 class Material(C.Structure):
     _fields_ = [
@@ -113,7 +117,7 @@ def host_lib() -> C.CDLL:
         lib.hrt_host_scene_add_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
         lib.hrt_host_scene_set_sky.argtypes = [C.c_void_p, C.c_int32]
         lib.hrt_host_scene_set_kd_params.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
-        lib.hrt_host_scene_flatten.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.hrt_host_scene_flatten.argtypes = [C.c_void_p, C.c_void_p]
         lib.hrt_host_scene_kd_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.hrt_host_default_camera.argtypes = [C.c_float, C.POINTER(Camera)]
         lib.hrt_host_default_camera.restype = None
@@ -224,8 +228,9 @@ class HostScene:
 
     def flatten(self) -> C.c_void_p:
         """Builds the KD-trees; returns ``const hrt_scene_desc*`` (valid until the next flatten / close)."""
-        d = C.c_void_p()
+        d = SceneDescPtr()
         self._check(self._lib.hrt_host_scene_flatten(self._h, C.byref(d)))
+        d._owner = self
         return d
 
     def kd_stats(self, mesh: int = 0) -> dict:

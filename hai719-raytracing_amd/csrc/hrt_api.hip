@@ -1,0 +1,573 @@
+// libhrt.so -- C ABI (include/hrt.h) over the HIP kernels in hrt_kernels.hip.
+// gfx950 only.  No CPU fallback: every entry point that needs the GPU fails
+// with HRT_ERR_DEVICE when HIP cannot provide one.
+#include "hrt_kernels.hip"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(HRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    int cus = 0;
+    int blocks_per_cu = 0;
+    uint32_t lds_budget = 0;  // bytes of dynamic LDS per workgroup for nodelets
+    hipFuncAttributes attr{};
+} g_rt;
+
+float as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct H3 { float x, y, z; };
+// host fp32 helpers in the reference's evaluation order (no contraction): these fold the
+// per-quad constants exactly as Square::intersect would compute them per call.
+H3 h_sub(H3 a, H3 b) {
+#pragma clang fp contract(off)
+    return H3{a.x - b.x, a.y - b.y, a.z - b.z};
+}
+H3 h_cross(H3 a, H3 b) {
+#pragma clang fp contract(off)
+    return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+float h_dot(H3 a, H3 b) {
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+float h_msub(float a, float b, float c, float d) {  // a*b - c*d, each product rounded first
+#pragma clang fp contract(off)
+    return a * b - c * d;
+}
+float h_len(H3 a) { return (float)std::sqrt((double)h_dot(a, a)); }
+H3 h_normalize(H3 a) {
+    float L = h_len(a);
+    return H3{a.x / L, a.y / L, a.z / L};
+}
+
+template <class T>
+int upload(const std::vector<T> &v, T **dptr) {
+    *dptr = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **)dptr, bytes));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HRT_OK;
+}
+
+}  // namespace
+
+struct hrt_scene {
+    DScene d{};
+    std::vector<void *> allocations;
+    uint32_t *tile_counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // scratch of hrt_render (whole frame on one GPU)
+    float *d_tiles = nullptr, *d_frame = nullptr;
+    size_t tiles_cap = 0, frame_cap = 0;
+    uint32_t last_grid = 0;
+};
+
+extern "C" {
+
+const char *hrt_last_error(void) { return g_error.c_str(); }
+
+int hrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int hrt_init(int device_ordinal) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(HRT_ERR_DEVICE, "hrt_init: no HIP device");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(HRT_ERR_INVALID, "hrt_init: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    g_rt.device = device_ordinal;
+    g_rt.cus = prop.multiProcessorCount;
+    HIP_TRY(hipFuncGetAttributes(&g_rt.attr, (const void *)hrt_trace_kernel));
+    // LDS for nodelets per 256-thread workgroup.  Default 32 KiB (4 workgroups/CU keep 128 of the
+    // CU's 160 KiB); HRT_LDS_KB overrides for tuning.
+    uint32_t kb = 32;
+    if (const char *e = std::getenv("HRT_LDS_KB")) kb = (uint32_t)std::max(0, atoi(e));
+    if (kb > 160) kb = 160;
+    g_rt.lds_budget = kb * 1024u;
+    if (g_rt.lds_budget > 64u * 1024u)
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)g_rt.lds_budget));
+    {   // u8 -> float tables in double, as the reference evaluates c/255. and c/127.5 - 1. (Material.cpp:87,124)
+        float lut[512];
+        for (int c = 0; c < 256; ++c) { lut[c] = (float)(c / 255.); lut[256 + c] = (float)(c / 127.5 - 1.); }
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof(lut)));
+    }
+    g_rt.ready = true;
+    return HRT_OK;
+}
+
+void hrt_shutdown(void) { g_rt.ready = false; }
+
+void hrt_scene_destroy(hrt_scene *s) {
+    if (!s) return;
+    for (void *p : s->allocations) (void)hipFree(p);
+    if (s->tile_counter) (void)hipFree(s->tile_counter);
+    if (s->d_tiles) (void)hipFree(s->d_tiles);
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
+    const hrt_scene_desc &D = *desc;
+    // ---- validation: every index the kernel will follow is checked here, on the host
+    for (uint32_t i = 0; i < D.n_materials; ++i) {
+        const hrt_material &m = D.materials[i];
+        if (m.image >= (int32_t)D.n_images || m.normal_map >= (int32_t)D.n_images)
+            return fail(HRT_ERR_INVALID, "material references an image that does not exist");
+        if (m.type < 0 || m.type > 2 || m.texture_type < 0 || m.texture_type > 2)
+            return fail(HRT_ERR_INVALID, "material type / texture type out of range");
+        if (m.normal_map >= 0 && (D.images[m.normal_map].w < 1 || D.images[m.normal_map].h < 1))
+            return fail(HRT_ERR_INVALID, "normal map image is empty");
+    }
+    for (uint32_t i = 0; i < D.n_spheres; ++i)
+        if (D.spheres[i].material < 0 || (uint32_t)D.spheres[i].material >= D.n_materials)
+            return fail(HRT_ERR_INVALID, "sphere material out of range");
+    for (uint32_t i = 0; i < D.n_quads; ++i)
+        if (D.quads[i].material < 0 || (uint32_t)D.quads[i].material >= D.n_materials)
+            return fail(HRT_ERR_INVALID, "quad material out of range");
+    if (D.skybox_image >= (int32_t)D.n_images) return fail(HRT_ERR_INVALID, "skybox image out of range");
+    if (D.n_lights && !D.lights) return fail(HRT_ERR_INVALID, "lights missing");
+
+    // ---- spheres / quads / lights / materials
+    std::vector<float4> spheres, quads, mats, lights;
+    for (uint32_t i = 0; i < D.n_spheres; ++i) {
+        const hrt_sphere &sp = D.spheres[i];
+        const hrt_material &m = D.materials[sp.material];
+        spheres.push_back(make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius));
+        spheres.push_back(make_float4(m.motion[0], m.motion[1], m.motion[2], as_float((uint32_t)sp.material)));
+    }
+    for (uint32_t i = 0; i < D.n_quads; ++i) {
+        const hrt_quad &q = D.quads[i];
+        const hrt_material &m = D.materials[q.material];
+        const H3 v0{q.v0[0], q.v0[1], q.v0[2]}, v1{q.v1[0], q.v1[1], q.v1[2]}, v3{q.v3[0], q.v3[1], q.v3[2]};
+        const H3 R = h_sub(v1, v0), U = h_sub(v3, v0);
+        const H3 n = h_normalize(h_cross(R, U));
+        uint32_t flags = 0;
+        if (m.type == HRT_MAT_GLASS) flags |= HRT_QUAD_FLAG_GLASS;
+        if (m.motion[0] != 0.f || m.motion[1] != 0.f || m.motion[2] != 0.f) flags |= HRT_QUAD_FLAG_MOVING;
+        quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
+        quads.push_back(make_float4(n.x, n.y, n.z, as_float(flags)));
+        quads.push_back(make_float4(R.x, R.y, R.z, h_len(R)));
+        quads.push_back(make_float4(U.x, U.y, U.z, h_len(U)));
+        quads.push_back(make_float4(m.motion[0], m.motion[1], m.motion[2], as_float((uint32_t)q.material)));
+        quads.push_back(make_float4(q.tangent[0], q.tangent[1], q.tangent[2], 0.f));
+        quads.push_back(make_float4(q.bitangent[0], q.bitangent[1], q.bitangent[2], 0.f));
+    }
+    for (uint32_t i = 0; i < D.n_lights; ++i) {
+        const hrt_light &l = D.lights[i];
+        lights.push_back(make_float4(l.pos[0], l.pos[1], l.pos[2], l.radius));
+        lights.push_back(make_float4(l.color[0], l.color[1], l.color[2], 0.f));
+    }
+    for (uint32_t i = 0; i < D.n_materials; ++i) {
+        const hrt_material &m = D.materials[i];
+        mats.push_back(make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.transparency));
+        mats.push_back(make_float4(m.index_medium, as_float((uint32_t)m.type), as_float((uint32_t)m.texture_type),
+                                   as_float((uint32_t)(m.emissive ? 1 : 0))));
+        mats.push_back(make_float4(m.checker1[0], m.checker1[1], m.checker1[2], m.tex_scale_x));
+        mats.push_back(make_float4(m.checker2[0], m.checker2[1], m.checker2[2], m.tex_scale_y));
+        mats.push_back(make_float4(m.light_color[0], m.light_color[1], m.light_color[2], m.light_intensity));
+        mats.push_back(make_float4(as_float((uint32_t)m.image), as_float((uint32_t)m.normal_map), 0.f, 0.f));
+    }
+
+    // ---- images -> RGBA8 words
+    std::vector<DImage> images;
+    std::vector<uint32_t> texels;
+    for (uint32_t i = 0; i < D.n_images; ++i) {
+        const hrt_image &im = D.images[i];
+        DImage di;
+        di.offset = (uint32_t)texels.size();
+        di.w = im.w; di.h = im.h; di.pad = 0;
+        if (im.w >= 1 && im.h >= 1) {
+            if (!im.rgb) return fail(HRT_ERR_INVALID, "image without pixels");
+            const size_t n = (size_t)im.w * im.h;
+            for (size_t p = 0; p < n; ++p)
+                texels.push_back((uint32_t)im.rgb[3 * p] | ((uint32_t)im.rgb[3 * p + 1] << 8) | ((uint32_t)im.rgb[3 * p + 2] << 16));
+        }
+        images.push_back(di);
+    }
+
+    // ---- meshes: nodelets (refs rebased), leaf-ordered triangle soup, colours
+    std::vector<DMesh> meshes;
+    std::vector<uint4> units;
+    std::vector<float4> tris, colors;
+    std::vector<uint4> vids;
+    for (uint32_t mi = 0; mi < D.n_meshes; ++mi) {
+        const hrt_mesh &M = D.meshes[mi];
+        if (M.material < 0 || (uint32_t)M.material >= D.n_materials) return fail(HRT_ERR_INVALID, "mesh material out of range");
+        for (uint32_t k = 0; k < 3 * M.n_triangles; ++k)
+            if (M.indices[k] >= M.n_vertices) return fail(HRT_ERR_INVALID, "mesh vertex index out of range");
+        if (M.n_triangles && (M.kd_root == HRT_KD_NIL || !M.kd_units || !M.n_kd_units))
+            return fail(HRT_ERR_INVALID, "mesh has triangles but no flattened KD-tree");
+        DMesh dm;
+        std::memset(&dm, 0, sizeof(dm));
+        for (int a = 0; a < 3; ++a) {
+            dm.aabb_lo[a] = M.aabb_min[a]; dm.aabb_hi[a] = M.aabb_max[a];
+            dm.kd_lo[a] = M.kd_min[a]; dm.kd_hi[a] = M.kd_max[a];
+        }
+        const uint32_t unit_base = (uint32_t)units.size();
+        const uint32_t tri_base = (uint32_t)(tris.size() / HRT_TRI_ROWS);
+        auto rebase = [&](uint32_t ref, bool &ok) -> uint32_t {
+            if (ref == HRT_KD_NIL) return ref;
+            const uint32_t idx = ref & ~HRT_KD_LEAF;
+            const uint32_t need = (ref & HRT_KD_LEAF) ? 4u : 1u;
+            if (idx + need > M.n_kd_units) ok = false;
+            return (idx + unit_base) | (ref & HRT_KD_LEAF);
+        };
+        // Walk the tree from the root so that only reachable, well-formed nodelets are accepted.
+        units.resize(unit_base + M.n_kd_units, make_uint4(0, 0, 0, 0));
+        if (M.n_triangles) {
+            std::vector<uint32_t> stack{M.kd_root};
+            std::vector<uint8_t> seen(M.n_kd_units, 0);
+            bool ok = true;
+            { bool o2 = true; (void)rebase(M.kd_root, o2); ok = o2; }
+            while (ok && !stack.empty()) {
+                const uint32_t ref = stack.back();
+                stack.pop_back();
+                const uint32_t idx = ref & ~HRT_KD_LEAF;
+                if (seen[idx]) continue;
+                seen[idx] = 1;
+                const hrt_kdunit *u = M.kd_units + idx;
+                if (ref & HRT_KD_LEAF) {
+                    if ((uint64_t)u[0].w[3] + u[1].w[3] > M.n_leaf_tris) { ok = false; break; }
+                    units[unit_base + idx] = make_uint4(u[0].w[0], u[0].w[1], u[0].w[2], u[0].w[3]);
+                    units[unit_base + idx + 1] = make_uint4(u[1].w[0], u[1].w[1], u[1].w[2], u[1].w[3]);
+                    uint32_t r[6];
+                    for (int f = 0; f < 4; ++f) r[f] = rebase(u[2].w[f], ok);
+                    r[4] = rebase(u[3].w[0], ok);
+                    r[5] = rebase(u[3].w[1], ok);
+                    units[unit_base + idx + 2] = make_uint4(r[0], r[1], r[2], r[3]);
+                    units[unit_base + idx + 3] = make_uint4(r[4], r[5], 0, 0);
+                } else {
+                    if (u->w[1] > 2u) { ok = false; break; }
+                    const uint32_t l = rebase(u->w[2], ok), r = rebase(u->w[3], ok);
+                    if (u->w[2] == HRT_KD_NIL || u->w[3] == HRT_KD_NIL) { ok = false; break; }
+                    units[unit_base + idx] = make_uint4(u->w[0], u->w[1], l, r);
+                    stack.push_back(u->w[2]);
+                    stack.push_back(u->w[3]);
+                }
+            }
+            if (!ok) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree");
+            bool o2 = true;
+            dm.root = rebase(M.kd_root, o2);
+        } else {
+            dm.root = HRT_KD_NIL;
+        }
+        // triangle soup in leaf order
+        for (uint32_t k = 0; k < M.n_leaf_tris; ++k) {
+            const uint32_t t = M.leaf_tris[k];
+            if (t >= M.n_triangles) return fail(HRT_ERR_INVALID, "leaf triangle id out of range");
+            H3 c[3];
+            for (int j = 0; j < 3; ++j) {
+                const float *p = M.positions + 3 * (size_t)M.indices[3 * (size_t)t + j];
+                c[j] = H3{p[0] * HRT_TRIANGLE_SCALING, p[1] * HRT_TRIANGLE_SCALING, p[2] * HRT_TRIANGLE_SCALING};
+            }
+            // Triangle(c0,c1,c2) + computeBarycentricCoordinates constants (Triangle.h:26-37, 62-70)
+            const H3 e1 = h_sub(c[1], c[0]), e2 = h_sub(c[2], c[0]);
+            const H3 nn = h_cross(e1, e2);
+            const float norm = h_len(nn);
+            const H3 n{nn.x / norm, nn.y / norm, nn.z / norm};
+            const float d00 = h_dot(e1, e1), d01 = h_dot(e1, e2), d11 = h_dot(e2, e2);
+            const float denom = h_msub(d00, d11, d01, d01);
+            tris.push_back(make_float4(c[0].x, c[0].y, c[0].z, as_float(t)));
+            tris.push_back(make_float4(e1.x, e1.y, e1.z, d00));
+            tris.push_back(make_float4(e2.x, e2.y, e2.z, d01));
+            tris.push_back(make_float4(n.x, n.y, n.z, h_dot(c[0], n)));
+            tris.push_back(make_float4(d11, denom, 0.f, 0.f));
+        }
+        dm.tri_base = tri_base;
+        dm.material = (uint32_t)M.material;
+        dm.color_type = HRT_COLOR_NONE;
+        if (M.color_type == HRT_COLOR_FACE && M.face_colors) {
+            dm.color_type = HRT_COLOR_FACE;
+            dm.color_base = (uint32_t)colors.size();
+            for (uint32_t t = 0; t < M.n_triangles; ++t)
+                colors.push_back(make_float4(M.face_colors[3 * t], M.face_colors[3 * t + 1], M.face_colors[3 * t + 2], 0.f));
+        } else if (M.color_type == HRT_COLOR_VERTEX && M.vert_colors) {
+            dm.color_type = HRT_COLOR_VERTEX;
+            dm.vcolor_base = (uint32_t)colors.size();
+            for (uint32_t v = 0; v < M.n_vertices; ++v)
+                colors.push_back(make_float4(M.vert_colors[3 * v], M.vert_colors[3 * v + 1], M.vert_colors[3 * v + 2], 0.f));
+            dm.color_base = (uint32_t)vids.size();
+            for (uint32_t t = 0; t < M.n_triangles; ++t)
+                vids.push_back(make_uint4(M.indices[3 * t], M.indices[3 * t + 1], M.indices[3 * t + 2], 0));
+        }
+        meshes.push_back(dm);
+    }
+
+    // ---- upload
+    DScene &d = s->d;
+    float4 *p4 = nullptr;
+    int rc;
+#define UP(vec, field, type)                                     \
+    {                                                            \
+        type *ptr = nullptr;                                     \
+        if ((rc = upload(vec, &ptr)) != HRT_OK) return rc;       \
+        s->allocations.push_back(ptr);                           \
+        d.field = ptr;                                           \
+    }
+    (void)p4;
+    UP(spheres, spheres, float4)
+    UP(quads, quads, float4)
+    UP(mats, materials, float4)
+    UP(meshes, meshes, DMesh)
+    UP(units, kd_units, uint4)
+    UP(tris, tris, float4)
+    UP(colors, colors, float4)
+    UP(vids, tri_vids, uint4)
+    UP(images, images, DImage)
+    UP(texels, texels, uint32_t)
+    UP(lights, lights, float4)
+#undef UP
+    d.n_spheres = D.n_spheres; d.n_quads = D.n_quads; d.n_meshes = D.n_meshes; d.n_lights = D.n_lights;
+    d.n_images = D.n_images;
+    d.n_kd_units = (uint32_t)units.size();
+    d.lds_units = std::min<uint32_t>(d.n_kd_units, g_rt.lds_budget / 16u);
+    d.dark_sky = D.dark_sky;
+    d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
+    HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    return HRT_OK;
+}
+
+int hrt_scene_create(const hrt_scene_desc *desc, hrt_scene **out) {
+    if (!desc || !out) return fail(HRT_ERR_INVALID, "hrt_scene_create: NULL argument");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_scene_create: call hrt_init first");
+    hrt_scene *s = nullptr;
+    try {
+        s = new hrt_scene();
+        int rc = scene_create_impl(desc, s);
+        if (rc != HRT_OK) {
+            std::string keep = g_error;
+            hrt_scene_destroy(s);
+            g_error = keep;
+            return rc;
+        }
+    } catch (const std::exception &e) {
+        if (s) hrt_scene_destroy(s);
+        return fail(HRT_ERR_STATE, e.what());
+    }
+    *out = s;
+    return HRT_OK;
+}
+
+uint32_t hrt_tiles_total(uint32_t w, uint32_t h) { return ((w + HRT_TILE - 1) / HRT_TILE) * ((h + HRT_TILE - 1) / HRT_TILE); }
+uint32_t hrt_tiles_owned(uint32_t w, uint32_t h, uint32_t rank, uint32_t world) {
+    const uint32_t t = hrt_tiles_total(w, h);
+    if (!world || rank >= t) return 0;
+    return (t - rank + world - 1) / world;
+}
+
+static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
+                       uint32_t flags, uint32_t rank, uint32_t world, DRender &R) {
+    if (!s || !cam) return fail(HRT_ERR_INVALID, "render: NULL argument");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "render: call hrt_init first");
+    if (!w || !h || !spp) return fail(HRT_ERR_INVALID, "render: w, h and spp must be positive");
+    if ((uint64_t)w * h > 0x7fffffffull) return fail(HRT_ERR_INVALID, "render: image too large");
+    if (!world || rank >= world) return fail(HRT_ERR_INVALID, "render: bad rank/world");
+    R.scene = s->d;
+    if (flags & HRT_FLAG_NO_LDS_TREE) R.scene.lds_units = 0;
+    // Inverse modelview / projection of the GL camera the reference reads back (matrixUtilities.h:33-50),
+    // in closed form, fp64, column-major: modelview = [right; up; -forward] * translate(-eye),
+    // projection = gluPerspective(fovy, aspect, znear, zfar) (Camera.cpp:41-50).
+    {
+        double *mi = R.cam.mv_inv, *pi = R.cam.p_inv;
+        for (int k = 0; k < 16; ++k) { mi[k] = 0.0; pi[k] = 0.0; }
+        for (int r = 0; r < 3; ++r) {
+            mi[0 + r] = (double)cam->right[r];
+            mi[4 + r] = (double)cam->up[r];
+            mi[8 + r] = -(double)cam->forward[r];
+            mi[12 + r] = (double)cam->eye[r];
+        }
+        mi[15] = 1.0;
+        const double rad = (double)cam->fovy_deg / 2.0 * M_PI / 180.0;
+        const double cot = std::cos(rad) / std::sin(rad);
+        const double dz = (double)cam->zfar - (double)cam->znear;
+        const double pa = cot / (double)cam->aspect, pb = cot;
+        const double pc = -((double)cam->zfar + (double)cam->znear) / dz, pd = -2.0 * (double)cam->znear * (double)cam->zfar / dz;
+        pi[0] = 1.0 / pa; pi[5] = 1.0 / pb; pi[11] = 1.0 / pd; pi[14] = -1.0; pi[15] = pc / pd;
+        for (int a = 0; a < 3; ++a) R.cam.eye[a] = (float)(mi[12 + a] / mi[15]);
+        R.cam.pad = 0.f;
+    }
+    R.w = w; R.h = h; R.spp = spp;
+    R.seed_lo = (uint32_t)seed; R.seed_hi = (uint32_t)(seed >> 32);
+    R.flags = flags;
+    R.rank = rank; R.world = world;
+    R.tiles_x = (w + HRT_TILE - 1) / HRT_TILE;
+    R.tiles_total = hrt_tiles_total(w, h);
+    R.tiles_owned = hrt_tiles_owned(w, h, rank, world);
+    R.tile_counter = s->tile_counter;
+    return HRT_OK;
+}
+
+int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
+                     uint32_t flags, uint32_t rank, uint32_t world, float *d_tiles, void *stream_) {
+    DRender R;
+    int rc = fill_render(s, cam, w, h, spp, seed, flags, rank, world, R);
+    if (rc != HRT_OK) return rc;
+    if (!d_tiles) return fail(HRT_ERR_INVALID, "hrt_render_tiles: NULL output");
+    R.out_tiles = d_tiles;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
+    const uint32_t lds_bytes = R.scene.lds_units * 16u;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)hrt_trace_kernel, 256, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    uint32_t grid = (uint32_t)(per_cu * g_rt.cus);
+    const uint32_t need = (R.tiles_owned + 3u) / 4u;  // 4 waves per workgroup, one tile per wave at a time
+    if (grid > need) grid = need;
+    s->last_grid = grid;
+    HIP_TRY(hipMemsetAsync(s->tile_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(256), lds_bytes, stream, R);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+    s->timed = true;
+    return HRT_OK;
+}
+
+int hrt_last_kernel_ms(hrt_scene *s, double *ms) {
+    if (!s || !ms) return fail(HRT_ERR_INVALID, "hrt_last_kernel_ms: NULL argument");
+    if (!s->timed) { *ms = 0.0; return HRT_OK; }
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, s->ev0, s->ev1));
+    *ms = (double)f;
+    return HRT_OK;
+}
+
+int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded, uint32_t w, uint32_t h, uint32_t world,
+                       float *d_frame, void *stream_) {
+    if (!d_gathered || !d_frame || !w || !h || !world) return fail(HRT_ERR_INVALID, "hrt_assemble_frame: bad argument");
+    if (tiles_per_rank_padded < hrt_tiles_owned(w, h, 0, world))
+        return fail(HRT_ERR_INVALID, "hrt_assemble_frame: tiles_per_rank_padded too small");
+    const uint32_t n = w * h;
+    hipLaunchKernelGGL(hrt_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_gathered,
+                       tiles_per_rank_padded, w, h, world, d_frame);
+    HIP_TRY(hipGetLastError());
+    return HRT_OK;
+}
+
+int hrt_kernel_info(hrt_stats *out) {
+    if (!out) return fail(HRT_ERR_INVALID, "hrt_kernel_info: NULL argument");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_kernel_info: call hrt_init first");
+    std::memset(out, 0, sizeof(*out));
+    out->vgprs = (uint32_t)g_rt.attr.numRegs;
+    out->lds_bytes = g_rt.lds_budget;
+    return HRT_OK;
+}
+
+int hrt_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed, uint32_t flags,
+               float *out_rgb, hrt_stats *stats) {
+    if (!out_rgb) return fail(HRT_ERR_INVALID, "hrt_render: NULL output");
+    if (!s) return fail(HRT_ERR_INVALID, "hrt_render: NULL scene");
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t tiles = hrt_tiles_total(w, h);
+    const size_t tile_floats = tiles * 64 * 3, frame_floats = (size_t)w * h * 3;
+    if (s->tiles_cap < tile_floats) {
+        if (s->d_tiles) (void)hipFree(s->d_tiles);
+        s->d_tiles = nullptr; s->tiles_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_tiles, tile_floats * sizeof(float)));
+        s->tiles_cap = tile_floats;
+    }
+    if (s->frame_cap < frame_floats) {
+        if (s->d_frame) (void)hipFree(s->d_frame);
+        s->d_frame = nullptr; s->frame_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_frame, frame_floats * sizeof(float)));
+        s->frame_cap = frame_floats;
+    }
+    int rc = hrt_render_tiles(s, cam, w, h, spp, seed, flags, 0, 1, s->d_tiles, nullptr);
+    if (rc != HRT_OK) return rc;
+    rc = hrt_assemble_frame(s->d_tiles, (uint32_t)tiles, w, h, 1, s->d_frame, nullptr);
+    if (rc != HRT_OK) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, s->d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        double ms = 0.0;
+        (void)hrt_last_kernel_ms(s, &ms);
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->samples = (uint64_t)w * h * spp;
+        stats->vgprs = (uint32_t)g_rt.attr.numRegs;
+        stats->lds_bytes = s->d.lds_units * 16u;
+        stats->waves_launched = s->last_grid * 4u;
+    }
+    return HRT_OK;
+}
+
+int hrt_render_aov(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t which, float *out_rgb) {
+    if (!out_rgb || which > 3u) return fail(HRT_ERR_INVALID, "hrt_render_aov: bad argument");
+    DRender R;
+    int rc = fill_render(s, cam, w, h, 1, 0, 0, 0, 1, R);
+    if (rc != HRT_OK) return rc;
+    float *d = nullptr;
+    const size_t bytes = (size_t)w * h * 3 * sizeof(float);
+    HIP_TRY(hipMalloc((void **)&d, bytes));
+    hipLaunchKernelGGL(hrt_aov_kernel, dim3((w * h + 255) / 256), dim3(256), 0, 0, R, which, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(HRT_ERR_DEVICE, std::string("hrt_render_aov: ") + hipGetErrorString(e));
+    return HRT_OK;
+}
+
+int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out) {
+    if (!out || !n) return fail(HRT_ERR_INVALID, "hrt_debug_path_stream: bad argument");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_debug_path_stream: call hrt_init first");
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, n * sizeof(float)));
+    hipLaunchKernelGGL(hrt_stream_kernel, dim3(1), dim3(64), 0, 0, (uint32_t)seed, (uint32_t)(seed >> 32), pixel, sample, n, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(HRT_ERR_DEVICE, std::string("hrt_debug_path_stream: ") + hipGetErrorString(e));
+    return HRT_OK;
+}
+
+// main.cpp:252-262: "P3", one line of "(int)(255*min(1,c))" triples.
+int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h) {
+    if (!path || !rgb) return fail(HRT_ERR_INVALID, "hrt_write_ppm: NULL argument");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(HRT_ERR_IO, std::string("Could not open file: ") + path);
+    std::fprintf(f, "P3\n%u %u\n255\n", w, h);
+    const size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; ++i) {
+        int c[3];
+        for (int k = 0; k < 3; ++k) c[k] = (int)(255.f * std::min<float>(1.f, rgb[3 * i + k]));
+        std::fprintf(f, "%d %d %d ", c[0], c[1], c[2]);
+    }
+    std::fprintf(f, "\n");
+    std::fclose(f);
+    return HRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Device-side scene layout of the MI355X trace path (gfx950 only).
+//
+// hrt_scene_create() repacks the hrt_scene_desc into the arrays below, all
+// resident in HBM for the life of the scene (they total a few MB, so after the
+// first touch they live in the per-XCD L2 / Infinity Cache; the top of every
+// KD-tree is additionally staged into LDS by each workgroup).
+//
+//   prim records  float4 rows, read with wave-uniform indices (scalar loads):
+//     sphere  2 rows: {c.xyz, r} {motion.xyz, material}
+//     quad    5 rows: {p0.xyz, D0} {n.xyz, flags} {R.xyz, |R|} {U.xyz, |U|} {motion.xyz, material}
+//             + 2 rows used only when shading: {T.xyz,0} {B.xyz,0}
+//   materials     6 float4 rows per material, read per lane at the closest hit
+//   meshes        DMesh records (wave-uniform)
+//   kd units      uint4 nodelets (include/hrt.h), refs rebased to the global array
+//   triangles     leaf-ordered soup, 5 float4 rows: {c0, id} {e1, d00} {e2, d01} {n, D} {d11, denom, -, -}
+//                 (Triangle.h:32-37, 62-75 constants folded on the host in the reference's arithmetic)
+//   colours       float4 per face / per vertex (+ uint4 vertex ids per triangle)
+//   texels        RGBA8 packed in a u32, one table entry {offset, w, h} per image
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hrt.h"
+
+#define HRT_QUAD_ROWS 7
+#define HRT_SPHERE_ROWS 2
+#define HRT_MAT_ROWS 6
+#define HRT_TRI_ROWS 5
+#define HRT_QUAD_FLAG_GLASS 1u
+#define HRT_QUAD_FLAG_MOVING 2u
+
+struct DMesh {
+    float aabb_lo[3], aabb_hi[3];  // Mesh::computeAABB box (the reference's gate test)
+    float kd_lo[3], kd_hi[3];      // root cell of the flattened tree
+    uint32_t root;                 // rebased ref
+    uint32_t tri_base;             // first row-triple of this mesh in the soup (in triangles, not rows)
+    uint32_t material;
+    int32_t color_type;
+    uint32_t color_base;           // into colours (face) or into vert ids / vertex colours
+    uint32_t vcolor_base;
+    uint32_t pad0, pad1;
+};
+
+struct DImage {
+    uint32_t offset;  // into texels
+    int32_t w, h;
+    uint32_t pad;
+};
+
+struct DScene {
+    const float4 *spheres;
+    const float4 *quads;
+    const float4 *materials;
+    const DMesh *meshes;
+    const uint4 *kd_units;
+    const float4 *tris;
+    const float4 *colors;
+    const uint4 *tri_vids;
+    const DImage *images;
+    const uint32_t *texels;
+    const float4 *lights;  // 2 rows: {pos.xyz, radius} {color.xyz, 0}
+    uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
+    uint32_t n_kd_units;
+    uint32_t lds_units;  // how many leading kd units each workgroup stages into LDS
+    int32_t dark_sky, skybox_image;
+};
+
+struct DCamera {
+    double mv_inv[16];  // inverse modelview, column-major (matrixUtilities.h:36)
+    double p_inv[16];   // inverse projection (matrixUtilities.h:42)
+    float eye[3];       // cameraSpaceToWorldSpace(0,0,0), matrixUtilities.h:53-58
+    float pad;
+};
+
+struct DRender {
+    DScene scene;
+    DCamera cam;
+    uint32_t w, h, spp;
+    uint32_t seed_lo, seed_hi;
+    uint32_t flags;
+    uint32_t rank, world;
+    uint32_t tiles_x, tiles_total, tiles_owned;
+    float *out_tiles;          // tiles_owned * 64 * 3 floats, tile-major
+    uint32_t *tile_counter;    // work queue head, zeroed before every launch
+};

@@ -203,3 +203,21 @@ void hrt_host_default_camera(float aspect_ratio, hrt_camera *out) {
 }
 
 }  // extern "C"
+
+// PPM loader probe: loads `path` with the host loader and returns its size and the FNV-1a hash of
+// its RGB bytes (parity check against the reference's imageLoader.cpp, tests/golden/ref_ppm.json).
+extern "C" int hrt_host_ppm_info(const char *path, int32_t *w, int32_t *h, uint64_t *fnv1a) {
+    if (!path || !w || !h || !fnv1a) return fail(HRT_ERR_INVALID, "hrt_host_ppm_info: NULL argument");
+    ppmLoader::ImageRGB img;
+    if (!ppmLoader::load_ppm(img, path)) return fail(HRT_ERR_IO, std::string("cannot read ") + path);
+    *w = img.w;
+    *h = img.h;
+    uint64_t sum = 1469598103934665603ull;
+    for (const ppmLoader::RGB &px : img.data) {
+        sum = (sum ^ px.r) * 1099511628211ull;
+        sum = (sum ^ px.g) * 1099511628211ull;
+        sum = (sum ^ px.b) * 1099511628211ull;
+    }
+    *fnv1a = sum;
+    return HRT_OK;
+}

@@ -1,0 +1,78 @@
+// Headless driver: what the reference does on key 'r' (main.cpp:321-325 ->
+// ray_trace_from_camera(), main.cpp:200-263), with the GLUT window replaced by
+// command-line arguments.  Scene set-up stays in host C++; the per-pixel x
+// per-sample loop runs on the GPU behind hrt_render().
+//
+//   raytracer [--scene cornell_box|cornell_mesh|random_spheres|mesh_in_box|backrooms_pool]
+//             [--w 850] [--h 480] [--spp 20] [--seed 1] [--out ./rendu.ppm] [--assets DIR] [--gpu 0]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/hrt.h"
+#include "scene.h"
+
+using namespace hrt_host;
+
+static unsigned int SCREENWIDTH = 850, SCREENHEIGHT = 480;  // main.cpp:52-53
+static unsigned int nsamples = 20;                          // DEFAULT_NSAMPLES, Constants.h:10
+static Scene scene;
+static hrt_scene *device_scene = nullptr;
+static uint64_t seed = 1;
+static std::string out_path = "./rendu.ppm";
+
+// Drop-in for ray_trace_from_camera(): same inputs (current scene, nsamples, window size, camera),
+// same output file and quantisation; returns non-zero instead of printing-and-returning on failure.
+static int ray_trace_from_camera() {
+    const unsigned w = SCREENWIDTH, h = SCREENHEIGHT;
+    std::vector<float> image((size_t)w * h * 3, 0.f);
+    const hrt_camera cam = default_camera((float)w / (float)h);
+    std::cout << "Ray tracing a " << w << " x " << h << " image on the GPU using " << nsamples
+              << " samples per pixel" << std::endl;
+    hrt_stats st;
+    int rc = hrt_render(device_scene, &cam, w, h, nsamples, seed, HRT_FLAG_GAMMA, image.data(), &st);
+    if (rc != HRT_OK) {
+        std::cout << "hrt_render failed: " << hrt_last_error() << std::endl;
+        return rc;
+    }
+    std::cout << "  Done in " << st.total_ms / 1000.0 << " seconds (kernel " << st.kernel_ms << " ms, "
+              << (double)st.samples / st.kernel_ms / 1e3 << " Msamples/s)" << std::endl;
+    rc = hrt_write_ppm(out_path.c_str(), image.data(), w, h);
+    if (rc != HRT_OK) std::cout << hrt_last_error() << std::endl;
+    return rc;
+}
+
+int main(int argc, char **argv) {
+    std::string name = "cornell_box", assets = "assets";
+    int gpu = 0;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        const std::string k = argv[i], v = argv[i + 1];
+        if (k == "--scene") name = v;
+        else if (k == "--w") SCREENWIDTH = (unsigned)atoi(v.c_str());
+        else if (k == "--h") SCREENHEIGHT = (unsigned)atoi(v.c_str());
+        else if (k == "--spp") nsamples = (unsigned)atoi(v.c_str());
+        else if (k == "--seed") seed = strtoull(v.c_str(), nullptr, 10);
+        else if (k == "--out") out_path = v;
+        else if (k == "--assets") assets = v;
+        else if (k == "--gpu") gpu = atoi(v.c_str());
+        else { std::cerr << "unknown option " << k << std::endl; return 2; }
+    }
+    scene.asset_root = assets;
+    if (!scene.setup_by_name(name, (float)SCREENWIDTH / (float)SCREENHEIGHT, seed)) {
+        std::cerr << scene.error << std::endl;
+        return EXIT_FAILURE;  // the reference exit()s on a missing mesh (Mesh.cpp:12-13)
+    }
+    std::unique_ptr<FlatScene> flat = scene.flatten();
+    if (hrt_init(gpu) != HRT_OK || hrt_scene_create(&flat->desc, &device_scene) != HRT_OK) {
+        std::cerr << hrt_last_error() << std::endl;
+        return EXIT_FAILURE;
+    }
+    int rc = ray_trace_from_camera();  // the 'r' key
+    hrt_scene_destroy(device_scene);
+    hrt_shutdown();
+    return rc == HRT_OK ? 0 : EXIT_FAILURE;
+}

@@ -205,6 +205,16 @@ int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded,
 int hrt_last_kernel_ms(hrt_scene *scene, double *ms);
 int hrt_kernel_info(hrt_stats *out);
 
+/* Parity instruments (deterministic, no RNG): first-hit AOVs through pixel
+ * centres at time 0.  which: 0 = (t, kind, index) with kind 1 sphere / 2 square /
+ * 3 mesh and index = object or triangle id (t = 0, index = -1 on a miss),
+ * 1 = shading normal, 2 = albedo, 3 = emission.  out_rgb: host, h*w*3. */
+int hrt_render_aov(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
+                   uint32_t which, float *out_rgb);
+/* Draws 0..n-1 of the per-path RNG stream (seed, pixel, sample) as the kernel
+ * produces them (DESIGN.md "RNG stream").  out: host, n floats. */
+int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out);
+
 /* Output stage of main.cpp:252-262: P3 ASCII with (int)(255*min(1,c)). */
 int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
 

@@ -62,6 +62,9 @@ int hrt_host_scene_kd_stats(hrt_host_scene *s, uint32_t mesh_index, uint32_t out
 
 void hrt_host_default_camera(float aspect_ratio, hrt_camera *out);
 
+/* PPM loader probe (imageLoader.cpp:21-103): size and FNV-1a hash of the RGB bytes of `path`. */
+int hrt_host_ppm_info(const char *path, int32_t *w, int32_t *h, uint64_t *fnv1a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,201 @@
+"""Host scene layer, C-ABI surface and the N>1 partition logic -- no GPU needed."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PKG, ROOT
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [(n, t) for pair in [("materials", "n_materials"), ("spheres", "n_spheres"), ("quads", "n_quads"),
+                                    ("meshes", "n_meshes"), ("lights", "n_lights"), ("images", "n_images")]
+                for n, t in ((pair[1], C.c_uint32), (pair[0], C.c_void_p))] + [("dark_sky", C.c_int32), ("skybox_image", C.c_int32)]
+
+
+def counts(desc):
+    d = C.cast(desc, C.POINTER(SceneDesc)).contents
+    return dict(materials=d.n_materials, spheres=d.n_spheres, quads=d.n_quads, meshes=d.n_meshes, lights=d.n_lights,
+                images=d.n_images, dark_sky=d.dark_sky)
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hrt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol(hrt):
+    """Both libraries load without a GPU and export exactly what include/*.h declares."""
+    dev_names = declared_functions("hrt.h")
+    host_names = declared_functions("hrt_host.h")
+    assert "hrt_render" in dev_names and "hrt_scene_create" in dev_names and "hrt_render_tiles" in dev_names
+    dev, host = hrt.device_lib(), hrt.host_lib()
+    for n in dev_names:
+        assert hasattr(dev, n), f"libhrt.so does not export {n}"
+    for n in host_names:
+        assert hasattr(host, n), f"libhrt_host.so does not export {n}"
+
+
+def test_device_library_fails_loudly_without_init(hrt):
+    """No silent fallback: before hrt_init (or with no GPU) the product path returns an error code."""
+    lib = hrt.device_lib()
+    host = hrt.HostScene().setup("cornell_box", 1.0, 1)
+    desc = host.flatten()
+    out = C.c_void_p()
+    if lib.hrt_device_count() == 0:
+        assert lib.hrt_init(0) < 0
+        rc = lib.hrt_scene_create(desc, C.byref(out))
+        assert rc < 0 and lib.hrt_last_error()
+        with pytest.raises(hrt.HrtError):
+            hrt.DeviceScene(desc)
+
+
+def test_config_scenes_have_the_reference_object_counts(hrt):
+    c = counts(hrt.HostScene().setup("cornell_box", 1.0, 1).flatten())
+    assert (c["spheres"], c["quads"], c["meshes"], c["lights"]) == (2, 11, 0, 0)  # Scene.h:421-619
+    assert c["images"] == 5 and c["dark_sky"] == 1
+    host = hrt.HostScene().setup("cornell_mesh", 16 / 9, 1)
+    c = counts(host.flatten())
+    assert (c["spheres"], c["quads"], c["meshes"]) == (2, 11, 1)
+    st = host.kd_stats(0)
+    assert st["leaves"] == st["inner"] + 1 and st["leaf_tri_refs"] >= 832
+    c = counts(hrt.HostScene().setup("random_spheres", 16 / 9, 1).flatten())
+    assert (c["spheres"], c["quads"], c["meshes"], c["lights"], c["dark_sky"]) == (82, 1, 0, 1, 0)  # Scene.h:829-924
+    c = counts(hrt.HostScene().setup("mesh_in_box", 16 / 9, 1).flatten())
+    assert (c["spheres"], c["quads"], c["meshes"]) == (0, 11, 1)
+
+
+def test_error_behaviour_of_the_host_layer(hrt, tmp_path):
+    with pytest.raises(hrt.HrtError, match="unknown scene"):
+        hrt.HostScene().setup("no_such_scene", 1.0, 1)
+    with pytest.raises(hrt.HrtError, match="cannot read"):  # the reference exit()s here (Mesh.cpp:12-13)
+        hrt.HostScene(str(tmp_path)).setup("cornell_mesh", 1.0, 1)
+    s = hrt.HostScene()
+    with pytest.raises(hrt.HrtError, match="out of range"):
+        s.add_mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32), hrt.Material.make())
+
+
+def test_random_spheres_scene_is_seeded(hrt, oracle):
+    cam = hrt.default_camera(1.0)
+    imgs = []
+    for seed in (1, 1, 2):
+        d = hrt.HostScene().setup("random_spheres", 1.0, seed).flatten()
+        imgs.append(oracle.OracleScene(d).aov(cam, 48, 48)["hit"])
+    assert np.array_equal(imgs[0], imgs[1]) and not np.array_equal(imgs[0], imgs[2])
+
+
+@pytest.mark.parametrize("name", ["cornell_mesh", "mesh_in_box"])
+def test_flattened_rope_tree_equals_brute_force_and_reference_tree(hrt, oracle, name):
+    """Closest hit over a mesh: the product's flattened rope KD-tree (walked on the CPU by the oracle with
+    the kernel's algorithm), brute force (Mesh::intersectOld) and the reference-shaped tree agree exactly."""
+    host = hrt.HostScene().setup(name, 16 / 9, 1)
+    desc = host.flatten()
+    rng = np.random.default_rng(5)
+    n = 6000
+    o = rng.uniform(-3, 3, (n, 3))
+    d = (rng.uniform(-1.2, 1.2, (n, 3)) + np.array([0, -1, -0.5])) - o
+    o[: n // 2] = rng.uniform(-1, 1, (n // 2, 3)) * np.array([0.8, 1.0, 0.8]) + np.array([0, -1, -0.5])
+    d[: n // 2] = rng.normal(size=(n // 2, 3))
+    d[:6] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]  # axis-parallel rays
+    rays = np.concatenate([o, d, np.zeros((n, 1))], 1).astype(np.float32)
+    brute = oracle.mesh_query(desc, 0, oracle.MESH_BRUTE, rays)
+    ref = oracle.mesh_query(desc, 0, oracle.MESH_REF_TREE, rays)
+    rope = oracle.mesh_query(desc, 0, oracle.MESH_ROPE_TREE, rays)
+    assert brute[:, 0].sum() > 300
+    assert np.array_equal(brute, ref)
+    assert np.array_equal(brute, rope)
+
+
+def test_kd_builder_parameters_and_degenerate_meshes(hrt, oracle):
+    rng = np.random.default_rng(2)
+    # a single triangle, coplanar duplicates and an axis-aligned grid (planar splits)
+    cases = {
+        "one": (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.uint32)),
+        "dups": (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]] * 9, np.uint32)),
+    }
+    g = np.array([[x, y, 0.0] for y in range(6) for x in range(6)], np.float32)
+    idx = []
+    for y in range(5):
+        for x in range(5):
+            a = y * 6 + x
+            idx += [[a, a + 1, a + 7], [a, a + 7, a + 6]]
+    cases["grid"] = (g, np.array(idx, np.uint32))
+    for name, (v, t) in cases.items():
+        for leaf_max in (1, 4, 64):
+            s = hrt.HostScene()
+            s.set_kd_params(leaf_max, 0)
+            s.add_mesh(v, t, hrt.Material.make())
+            desc = s.flatten()
+            n = 2000
+            o = np.concatenate([rng.uniform(-1, 6, (n, 2)), np.full((n, 1), 3.0)], 1)
+            d = np.concatenate([rng.normal(0, 0.3, (n, 2)), np.full((n, 1), -1.0)], 1)
+            rays = np.concatenate([o, d, np.zeros((n, 1))], 1).astype(np.float32)
+            assert np.array_equal(oracle.mesh_query(desc, 0, oracle.MESH_BRUTE, rays)[:, :2],
+                                  oracle.mesh_query(desc, 0, oracle.MESH_ROPE_TREE, rays)[:, :2]), (name, leaf_max)
+
+
+def test_tile_partition_covers_every_pixel_once(hrt):
+    hdist = __import__("importlib").import_module("hai719-raytracing_amd.dist")
+    for (w, h) in [(64, 36), (61, 35), (8, 8), (1, 1), (9, 17)]:
+        for world in (1, 2, 3, 8):
+            seen = np.zeros((h, w), np.int32)
+            total = 0
+            for r in range(world):
+                tiles = hdist.tile_pixels(w, h, r, world)
+                assert len(tiles) == hrt.tiles_owned(w, h, r, world)
+                total += len(tiles)
+                for _, x0, y0 in tiles:
+                    seen[y0:y0 + 8, x0:x0 + 8] += 1
+            assert total == hrt.tiles_total(w, h) and (seen == 1).all()
+            assert hdist.padded_tiles_per_rank(w, h, world) >= max(hrt.tiles_owned(w, h, r, world) for r in range(world))
+
+
+WORKER = r'''
+import importlib, os, sys
+import numpy as np, torch, torch.distributed as dist
+ROOT = sys.argv[1]; out_path = sys.argv[2]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+hrt = importlib.import_module("hai719-raytracing_amd")
+hdist = importlib.import_module("hai719-raytracing_amd.dist")
+import oracle_lib as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+w, h, spp, seed = 43, 27, 2, 5     # ragged: 6 x 4 tiles, last column/row partial
+host = hrt.HostScene().setup("cornell_mesh", w / h, 1); desc = host.flatten(); cam = hrt.default_camera(w / h)
+full = O.OracleScene(desc).render(cam, w, h, spp, seed=seed, threads=2)   # per-pixel streams: any partition gives these pixels
+def fill(buf):   # stand-in for hrt_render_tiles on a CPU rank: this rank's tiles, tile-major, zero outside the image
+    a = np.zeros(tuple(buf.shape), np.float32)
+    for slot, x0, y0 in hdist.tile_pixels(w, h, rank, world):
+        t = np.zeros((8, 8, 3), np.float32)
+        hh, ww = min(8, h - y0), min(8, w - x0)
+        t[:hh, :ww] = full[y0:y0 + hh, x0:x0 + ww]
+        a[slot] = t.reshape(64, 3)
+    buf.copy_(torch.from_numpy(a))
+frame = hdist.render_frame_distributed(fill, w, h, rank, world, torch.device("cpu"), on_gpu=False)
+if rank == 0:
+    np.save(out_path, np.stack([frame.numpy(), full]))
+else:
+    assert frame is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_gather_of_tiles_gloo(hrt, oracle, tmp_path, world):
+    """N>1 path on CPU: tile partition -> ONE gather to rank 0 -> de-interleave == the single-rank frame."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "frame.npy"
+    port = 29500 + (os.getpid() % 2000) + world
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(out)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    frame, full = np.load(out)
+    assert np.array_equal(frame, full)
