@@ -129,7 +129,7 @@ def device_lib() -> C.CDLL:
     """The HIP library.  Raises if it has not been built -- there is no fallback."""
     global _dev
     if _dev is None:
-        lib = _load("libhrt.so")
+        lib = _load(os.environ.get("HRT_LIBNAME", "libhrt.so"))  # HRT_LIBNAME: A/B builds of the same ABI (tools/variants.sh)
         lib.hrt_last_error.restype = C.c_char_p
         lib.hrt_init.argtypes = [C.c_int]
         lib.hrt_shutdown.restype = None

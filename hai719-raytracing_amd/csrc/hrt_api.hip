@@ -73,11 +73,17 @@ int upload(const std::vector<T> &v, T **dptr) {
 }  // namespace
 
 struct hrt_scene {
-    DScene d{};
+    DScene d{};                  // host copy of the device scene header
+    DScene *d_scene = nullptr;   // the header in HBM (read by the kernels through a constant-space pointer)
+    DCamera *d_cam = nullptr;    // camera block in HBM, re-uploaded only when the camera changes
+    DCamera h_cam{};
+    bool cam_valid = false;
+    uint32_t lds_units = 0;
     std::vector<void *> allocations;
     uint32_t *tile_counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    float bound = 0.f;  // largest distance of any scene point from the origin (filter margins)
     // scratch of hrt_render (whole frame on one GPU)
     float *d_tiles = nullptr, *d_frame = nullptr;
     size_t tiles_cap = 0, frame_cap = 0;
@@ -111,9 +117,12 @@ int hrt_init(int device_ordinal) {
     if (const char *e = std::getenv("HRT_LDS_KB")) kb = (uint32_t)std::max(0, atoi(e));
     if (kb > 160) kb = 160;
     g_rt.lds_budget = kb * 1024u;
-    if (g_rt.lds_budget > 64u * 1024u)
+    if (g_rt.lds_budget > 64u * 1024u) {
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g_rt.lds_budget));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)g_rt.lds_budget));
+    }
     {   // u8 -> float tables in double, as the reference evaluates c/255. and c/127.5 - 1. (Material.cpp:87,124)
         float lut[512];
         for (int c = 0; c < 256; ++c) { lut[c] = (float)(c / 255.); lut[256 + c] = (float)(c / 127.5 - 1.); }
@@ -129,6 +138,8 @@ void hrt_scene_destroy(hrt_scene *s) {
     if (!s) return;
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->tile_counter) (void)hipFree(s->tile_counter);
+    if (s->d_scene) (void)hipFree(s->d_scene);
+    if (s->d_cam) (void)hipFree(s->d_cam);
     if (s->d_tiles) (void)hipFree(s->d_tiles);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -156,6 +167,32 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
             return fail(HRT_ERR_INVALID, "quad material out of range");
     if (D.skybox_image >= (int32_t)D.n_images) return fail(HRT_ERR_INVALID, "skybox image out of range");
     if (D.n_lights && !D.lights) return fail(HRT_ERR_INVALID, "lights missing");
+
+    // ---- scene extent: an upper bound on |point| for every point a ray can start from or hit
+    {
+        double b = 0.0;
+        auto grow = [&](double x, double y, double z, double extra) { b = std::max(b, std::sqrt(x * x + y * y + z * z) + extra); };
+        auto mlen = [&](const hrt_material &m) { return std::sqrt((double)m.motion[0] * m.motion[0] + (double)m.motion[1] * m.motion[1] + (double)m.motion[2] * m.motion[2]); };
+        for (uint32_t i = 0; i < D.n_spheres; ++i) {
+            const hrt_sphere &sp = D.spheres[i];
+            grow(sp.center[0], sp.center[1], sp.center[2], std::fabs((double)sp.radius) + mlen(D.materials[sp.material]));
+        }
+        for (uint32_t i = 0; i < D.n_quads; ++i) {
+            const hrt_quad &q = D.quads[i];
+            const double ml = mlen(D.materials[q.material]);
+            grow(q.v0[0], q.v0[1], q.v0[2], ml);
+            grow(q.v1[0], q.v1[1], q.v1[2], ml);
+            grow(q.v3[0], q.v3[1], q.v3[2], ml);
+            grow((double)q.v1[0] + q.v3[0] - q.v0[0], (double)q.v1[1] + q.v3[1] - q.v0[1], (double)q.v1[2] + q.v3[2] - q.v0[2], ml);
+        }
+        for (uint32_t mi = 0; mi < D.n_meshes; ++mi)
+            for (uint32_t v = 0; v < D.meshes[mi].n_vertices; ++v) {
+                const float *p = D.meshes[mi].positions + 3 * (size_t)v;
+                grow(p[0] * 1.00001, p[1] * 1.00001, p[2] * 1.00001, 0.0);
+            }
+        for (uint32_t i = 0; i < D.n_lights; ++i) grow(D.lights[i].pos[0], D.lights[i].pos[1], D.lights[i].pos[2], std::fabs((double)D.lights[i].radius));
+        s->bound = (float)b;
+    }
 
     // ---- spheres / quads / lights / materials
     std::vector<float4> spheres, quads, mats, lights;
@@ -350,12 +387,15 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     d.n_spheres = D.n_spheres; d.n_quads = D.n_quads; d.n_meshes = D.n_meshes; d.n_lights = D.n_lights;
     d.n_images = D.n_images;
     d.n_kd_units = (uint32_t)units.size();
-    d.lds_units = std::min<uint32_t>(d.n_kd_units, g_rt.lds_budget / 16u);
+    s->lds_units = std::min<uint32_t>(d.n_kd_units, g_rt.lds_budget / 16u);
     d.dark_sky = D.dark_sky;
     d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
     HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
+    HIP_TRY(hipMalloc((void **)&s->d_scene, sizeof(DScene)));
+    HIP_TRY(hipMemcpy(s->d_scene, &s->d, sizeof(DScene), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&s->d_cam, sizeof(DCamera)));
     return HRT_OK;
 }
 
@@ -388,19 +428,23 @@ uint32_t hrt_tiles_owned(uint32_t w, uint32_t h, uint32_t rank, uint32_t world) 
 }
 
 static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
-                       uint32_t flags, uint32_t rank, uint32_t world, DRender &R) {
+                       uint32_t flags, uint32_t rank, uint32_t world, DRender &R, hipStream_t stream) {
     if (!s || !cam) return fail(HRT_ERR_INVALID, "render: NULL argument");
     if (!g_rt.ready) return fail(HRT_ERR_STATE, "render: call hrt_init first");
     if (!w || !h || !spp) return fail(HRT_ERR_INVALID, "render: w, h and spp must be positive");
     if ((uint64_t)w * h > 0x7fffffffull) return fail(HRT_ERR_INVALID, "render: image too large");
     if (!world || rank >= world) return fail(HRT_ERR_INVALID, "render: bad rank/world");
-    R.scene = s->d;
-    if (flags & HRT_FLAG_NO_LDS_TREE) R.scene.lds_units = 0;
+    R.scene = s->d_scene;
+    R.cam = s->d_cam;
+    R.lds_units = (flags & HRT_FLAG_NO_LDS_TREE) ? 0u : s->lds_units;
+    R.err_abs = 2e-6f * (s->bound + std::sqrt(cam->eye[0] * cam->eye[0] + cam->eye[1] * cam->eye[1] + cam->eye[2] * cam->eye[2]) + 1.f);
+    DCamera C;
+    std::memset(&C, 0, sizeof(C));
     // Inverse modelview / projection of the GL camera the reference reads back (matrixUtilities.h:33-50),
     // in closed form, fp64, column-major: modelview = [right; up; -forward] * translate(-eye),
     // projection = gluPerspective(fovy, aspect, znear, zfar) (Camera.cpp:41-50).
     {
-        double *mi = R.cam.mv_inv, *pi = R.cam.p_inv;
+        double *mi = C.mv_inv, *pi = C.p_inv;
         for (int k = 0; k < 16; ++k) { mi[k] = 0.0; pi[k] = 0.0; }
         for (int r = 0; r < 3; ++r) {
             mi[0 + r] = (double)cam->right[r];
@@ -415,8 +459,13 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
         const double pa = cot / (double)cam->aspect, pb = cot;
         const double pc = -((double)cam->zfar + (double)cam->znear) / dz, pd = -2.0 * (double)cam->znear * (double)cam->zfar / dz;
         pi[0] = 1.0 / pa; pi[5] = 1.0 / pb; pi[11] = 1.0 / pd; pi[14] = -1.0; pi[15] = pc / pd;
-        for (int a = 0; a < 3; ++a) R.cam.eye[a] = (float)(mi[12 + a] / mi[15]);
-        R.cam.pad = 0.f;
+        for (int a = 0; a < 3; ++a) C.eye[a] = (float)(mi[12 + a] / mi[15]);
+    }
+    if (!s->cam_valid || std::memcmp(&C, &s->h_cam, sizeof(C)) != 0) {
+        // the previous launch may still be reading the old block: stream order makes the copy wait for it
+        s->h_cam = C;
+        HIP_TRY(hipMemcpyAsync(s->d_cam, &s->h_cam, sizeof(C), hipMemcpyHostToDevice, stream));
+        s->cam_valid = true;
     }
     R.w = w; R.h = h; R.spp = spp;
     R.seed_lo = (uint32_t)seed; R.seed_hi = (uint32_t)(seed >> 32);
@@ -432,15 +481,16 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
 int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
                      uint32_t flags, uint32_t rank, uint32_t world, float *d_tiles, void *stream_) {
     DRender R;
-    int rc = fill_render(s, cam, w, h, spp, seed, flags, rank, world, R);
+    int rc = fill_render(s, cam, w, h, spp, seed, flags, rank, world, R, (hipStream_t)stream_);
     if (rc != HRT_OK) return rc;
     if (!d_tiles) return fail(HRT_ERR_INVALID, "hrt_render_tiles: NULL output");
     R.out_tiles = d_tiles;
     hipStream_t stream = (hipStream_t)stream_;
     if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
-    const uint32_t lds_bytes = R.scene.lds_units * 16u;
+    const uint32_t lds_bytes = R.lds_units * 16u;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)hrt_trace_kernel, 256, lds_bytes));
+    const void *kfn = s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds_bytes));
     if (per_cu < 1) per_cu = 1;
     uint32_t grid = (uint32_t)(per_cu * g_rt.cus);
     const uint32_t need = (R.tiles_owned + 3u) / 4u;  // 4 waves per workgroup, one tile per wave at a time
@@ -448,9 +498,15 @@ int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h
     s->last_grid = grid;
     HIP_TRY(hipMemsetAsync(s->tile_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(256), lds_bytes, stream, R);
+    if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace_kernel_lights, dim3(grid), dim3(256), lds_bytes, stream, R);
+    else hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(256), lds_bytes, stream, R);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
+    if (flags & HRT_FLAG_GAMMA) {
+        const uint32_t n = R.tiles_owned * 64u * 3u;
+        hipLaunchKernelGGL(hrt_gamma_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_tiles, n);
+        HIP_TRY(hipGetLastError());
+    }
     s->timed = true;
     return HRT_OK;
 }
@@ -518,7 +574,7 @@ int hrt_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->samples = (uint64_t)w * h * spp;
         stats->vgprs = (uint32_t)g_rt.attr.numRegs;
-        stats->lds_bytes = s->d.lds_units * 16u;
+        stats->lds_bytes = s->lds_units * 16u;
         stats->waves_launched = s->last_grid * 4u;
     }
     return HRT_OK;
@@ -527,7 +583,7 @@ int hrt_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint
 int hrt_render_aov(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t which, float *out_rgb) {
     if (!out_rgb || which > 3u) return fail(HRT_ERR_INVALID, "hrt_render_aov: bad argument");
     DRender R;
-    int rc = fill_render(s, cam, w, h, 1, 0, 0, 0, 1, R);
+    int rc = fill_render(s, cam, w, h, 1, 0, 0, 0, 1, R, nullptr);
     if (rc != HRT_OK) return rc;
     float *d = nullptr;
     const size_t bytes = (size_t)w * h * 3 * sizeof(float);

@@ -62,7 +62,6 @@ struct DScene {
     const float4 *lights;  // 2 rows: {pos.xyz, radius} {color.xyz, 0}
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
     uint32_t n_kd_units;
-    uint32_t lds_units;  // how many leading kd units each workgroup stages into LDS
     int32_t dark_sky, skybox_image;
 };
 
@@ -73,14 +72,19 @@ struct DCamera {
     float pad;
 };
 
+// Kernel argument block: small on purpose.  The scene and the camera live in device memory and
+// are read through constant-address-space pointers (scalar loads at the point of use), which keeps
+// the SGPR file for exec masks and primitive rows instead of pinning 60+ SGPRs of arguments.
 struct DRender {
-    DScene scene;
-    DCamera cam;
+    const DScene *scene;
+    const DCamera *cam;
     uint32_t w, h, spp;
     uint32_t seed_lo, seed_hi;
     uint32_t flags;
     uint32_t rank, world;
     uint32_t tiles_x, tiles_total, tiles_owned;
+    uint32_t lds_units;        // leading kd units each workgroup stages into LDS
+    float err_abs;             // 2e-6 * (largest |coordinate| of scene + camera): margin of the no-division filters
     float *out_tiles;          // tiles_owned * 64 * 3 floats, tile-major
     uint32_t *tile_counter;    // work queue head, zeroed before every launch
 };

@@ -1,31 +1,39 @@
 // Hand-written HIP kernels of the trace path for gfx950 (CDNA4, wave64).
 //
-// hrt_trace_kernel is the persistent-wavefront megakernel: every wave pulls
-// 8x8-pixel tiles from a work-queue head, lane = pixel, and each lane runs the
-// reference's per-sample loop (main.cpp:183-198) as a bounce state machine
-// that regenerates its next camera sample the moment a path ends, so all 64
-// lanes stay busy until the tile's last sample.  Per bounce:
-//   ray generation            matrixUtilities.h:53-74 (fp64 mat-vec, as the reference)
-//   closest hit               Scene.h:202-230  spheres -> squares -> meshes
-//     sphere                  Sphere.h:91-132
-//     square                  Square.h:65-126
-//     mesh                    Mesh.cpp:112-117, KDTree.cpp:31-85 -- here a stackless walk of
-//                             the flattened rope KD-tree, nodelets served from LDS
-//     triangle                Triangle.h:62-126 on leaf-ordered rows with the per-triangle constants folded
-//   shading                   Scene.h:270-334 (texture, normal map, emission, lights, soft shadows)
-//   scatter                   Material.cpp:26-60
+// hrt_trace_kernel is the persistent-wavefront megakernel: every wave pulls 8x8-pixel tiles from a
+// work-queue head, lane = pixel, and each lane runs the reference's per-sample loop
+// (main.cpp:183-198) as a bounce state machine that regenerates its next camera sample the moment a
+// path ends, so lanes stay busy until the tile's last sample.  Per bounce a lane goes through
+//   stage A  ray generation     matrixUtilities.h:53-74 (fp64 mat-vec, as the reference)
+//            spheres, squares   Scene.h:202-222, Sphere.h:91-132, Square.h:65-126
+//            mesh gates         KDTree.cpp:82 / AABB.h:48-65
+//   stage B  mesh traversal     Mesh.cpp:112-117, KDTree.cpp:31-85 -- a stackless walk of the flattened
+//                               rope KD-tree (nodelets from LDS), triangles Triangle.h:62-126
+//   stage C  shading + scatter  Scene.h:270-342, Material.cpp:13-130
+// Only a few lanes of a wave have a ray that enters a mesh's box on a given bounce, so stage B is
+// DEFERRED: such lanes park (their ray and best-so-far hit stay in registers) while the others go on
+// with A and C; the wave runs B when __popcll(__ballot(parked)) reaches HRT_MESH_BATCH or nobody else
+// can make progress.  This is the per-wavefront compaction of divergent secondary rays: it is done in
+// time (ballot / popcount vote on which stage the wave executes next) rather than by moving rays
+// between lanes, so per-pixel sample order -- and therefore every pixel -- stays deterministic.
 //
-// NUMERICS.  This file is compiled with -ffp-contract=off and every geometric or
-// branch-deciding expression is written in the reference's operation order, with
-// its float/double promotions (the "fp64 islands" of SURVEY.md 7): given the same
-// ray and the same random numbers a lane takes the same decisions and produces the
-// same hit point as the reference arithmetic, bit for bit (IEEE fp32 add/mul/div/
-// sqrt are correctly rounded on gfx950).  What is NOT op-identical: the KD-tree walk
-// itself (a different tree; it only selects which triangles are tested), the radiance
-// sum (throughput form instead of the recursion's inside-out order, ~1e-7 relative)
-// and libm-level functions in fp64 (acos/atan2/asin/pow: different implementations,
-// equal after rounding to fp32 except on rare ties).
+// NUMERICS.  Compiled with -ffp-contract=off; every geometric or branch-deciding expression is written
+// in the reference's operation order with its float/double promotions (SURVEY.md 7 "fp64 islands"):
+// given the same ray and random numbers a lane takes the same decisions and reaches the same hit point
+// as the reference arithmetic, bit for bit (IEEE fp32 add/mul/div/sqrt are correctly rounded on
+// gfx950).  Cheap no-division FILTERS (approximate t, conservative margins) only choose which
+// primitives go through that exact arithmetic; they never decide a hit.  NOT op-identical: the KD-tree
+// walk itself (a different tree; it only selects which triangles are tested), the radiance sum
+// (throughput form instead of the recursion's inside-out order, ~1e-7 relative) and fp64 libm calls
+// (acos/atan2/asin/pow: other implementations, equal after rounding to fp32 except on rare ties).
 #include "hrt_device.h"
+
+#ifndef HRT_MESH_BATCH
+#define HRT_MESH_BATCH 16  // parked lanes that trigger a mesh stage (A/B on MI355X: 1 -> 45.4 ms, 16 -> 43.3, 32 -> 53.4)
+#endif
+#ifndef HRT_MIN_WAVES
+#define HRT_MIN_WAVES 4    // waves per SIMD the register allocator must leave room for
+#endif
 
 namespace hrtk {
 
@@ -38,24 +46,41 @@ namespace hrtk {
 // u8 -> float tables built on the host in double: [0,256) = c/255., [256,512) = c/127.5 - 1.
 __constant__ float c_u8_lut[512];
 
+// ---- address spaces -------------------------------------------------------------------------
+// constant (4): wave-uniform records -> scalar loads (s_load_dwordx4 into SGPRs).  The kernel also
+//               stores to out_tiles, so plain pointers would not be provably unclobbered.
+// global   (1): per-lane indexed rows -> global_load (not flat_load).
+// local    (3): nodelets staged in LDS -> ds_read_b128.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(4))) *cf4;
+typedef const v4f __attribute__((address_space(1))) *gf4;
+typedef const v4u __attribute__((address_space(1))) *gu4;
+typedef const uint32_t __attribute__((address_space(1))) *gu1;
+typedef const v4u __attribute__((address_space(3))) *lu4;
+typedef const DMesh __attribute__((address_space(4))) *cmesh;
+typedef const DScene __attribute__((address_space(4))) *cscene;
+typedef const DCamera __attribute__((address_space(4))) *ccam;
+typedef const DImage __attribute__((address_space(1))) *gimg;
+__device__ __forceinline__ float4 ld(cf4 p, uint32_t i) { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 ld(gf4 p, uint32_t i) { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 ld(gu4 p, uint32_t i) { const v4u v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 ld(lu4 p, uint32_t i) { const v4u v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+
 struct f3 {
     float x, y, z;
 };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 mk(const float4 &v) { return f3{v.x, v.y, v.z}; }
-__device__ __forceinline__ f3 mk(const float *p) { return f3{p[0], p[1], p[2]}; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(s * a.x, s * a.y, s * a.z); }
 __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // Vec3.h:48 order
-__device__ __forceinline__ f3 cross(f3 a, f3 b) {
-    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
 __device__ __forceinline__ float length(f3 a) { return sqrtf(dot(a, a)); }  // == (float)sqrt((double)x)
 __device__ __forceinline__ f3 normalize(f3 a) {  // Vec3.h:46: divide by the length, no guard
-    float L = length(a);
+    const float L = length(a);
     return mk(a.x / L, a.y / L, a.z / L);
 }
 __device__ __forceinline__ float comp(f3 a, uint32_t axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
@@ -97,6 +122,14 @@ struct Hit {
     float a0, a1;    // square: (u,v); mesh: barycentric (w1,w2)
 };
 
+// Everything a device function needs to reach the scene.
+struct Ctx {
+    cscene S;
+    lu4 lds;         // nodelets staged in LDS
+    uint32_t lds_n;  // how many
+    float err_abs;   // margin scale of the filters
+};
+
 // ------------------------------------------------------------------ primitives
 // Sphere.h:91-132; near root only (the far root is unreachable, N6).  2.*x is exact in fp32.
 __device__ __forceinline__ bool sphere_t(const float4 r0, const float4 r1, const Ray &ray, float &t) {
@@ -113,9 +146,10 @@ __device__ __forceinline__ bool sphere_t(const float4 r0, const float4 r1, const
 }
 
 // Square.h:65-126 with the per-quad constants (n, |R|, |U|, D0) folded on the host in the same arithmetic.
-__device__ __forceinline__ bool quad_t(const float4 *__restrict__ q, const Ray &ray, float tmax, float &t, float &u,
-                                       float &v) {
-    const float4 q0 = q[0], q1 = q[1];
+// Q = cf4 (wave-uniform quad, scalar rows) or gf4 (per-lane quad, vector rows).
+template <class Q>
+__device__ __forceinline__ bool quad_t(Q q, const Ray &ray, float tmax, float &t, float &u, float &v) {
+    const float4 q0 = ld(q, 0), q1 = ld(q, 1);
     const uint32_t flags = __float_as_uint(q1.w);
     const f3 n = mk(q1);
     const float dotRN = dot(ray.d, n);
@@ -124,12 +158,12 @@ __device__ __forceinline__ bool quad_t(const float4 *__restrict__ q, const Ray &
     f3 p0 = mk(q0);
     float D = q0.w;
     if (flags & HRT_QUAD_FLAG_MOVING) {
-        p0 = p0 + ray.time * mk(q[4]);
+        p0 = p0 + ray.time * mk(ld(q, 4));
         D = dot(p0, n);
     }
     t = (D - dot(ray.o, n)) / dotRN;
     if (!HRT_T_ACCEPT(t) || !(t < tmax)) return false;
-    const float4 q2 = q[2], q3 = q[3];
+    const float4 q2 = ld(q, 2), q3 = ld(q, 3);
     const f3 qq = (ray.o + t * ray.d) - p0;
     const float proj1 = dot(qq, mk(q2)) / q2.w;
     const float proj2 = dot(qq, mk(q3)) / q3.w;
@@ -140,15 +174,15 @@ __device__ __forceinline__ bool quad_t(const float4 *__restrict__ q, const Ray &
 }
 
 // AABB.h:48-65 exactly: reciprocal in double, products narrowed to float.
-__device__ __forceinline__ bool aabb_gate(const float *lo, const float *hi, const Ray &ray) {
+__device__ __forceinline__ bool aabb_gate_exact(cmesh M, const Ray &ray) {
     float tmin = HRT_EPS, tmax = HRT_FLT_MAX;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float da = a == 0 ? ray.d.x : (a == 1 ? ray.d.y : ray.d.z);
         const float oa = a == 0 ? ray.o.x : (a == 1 ? ray.o.y : ray.o.z);
         const double adinv = 1.0 / (double)da;
-        const float t0 = (float)((double)(lo[a] - oa) * adinv);
-        const float t1 = (float)((double)(hi[a] - oa) * adinv);
+        const float t0 = (float)((double)(M->aabb_lo[a] - oa) * adinv);
+        const float t1 = (float)((double)(M->aabb_hi[a] - oa) * adinv);
         if (t0 < t1) {
             if (t0 > tmin) tmin = t0;
             if (t1 < tmax) tmax = t1;
@@ -161,134 +195,252 @@ __device__ __forceinline__ bool aabb_gate(const float *lo, const float *hi, cons
     return true;
 }
 
+// KDTree.cpp:82 gate.  An fp32 slab test with a margin settles the clear cases (each slab distance
+// differs from the reference's by <= 3e-7 |t|); only a ray that grazes the box within the margin, or
+// has a zero direction component, pays for the exact fp64 form.
+__device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) {
+    float g0 = HRT_EPS, g1 = HRT_FLT_MAX, big = 0.f;
+    float t0 = (M->aabb_lo[0] - ray.o.x) * inv.x, t1 = (M->aabb_hi[0] - ray.o.x) * inv.x;
+    g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
+    t0 = (M->aabb_lo[1] - ray.o.y) * inv.y; t1 = (M->aabb_hi[1] - ray.o.y) * inv.y;
+    g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
+    t0 = (M->aabb_lo[2] - ray.o.z) * inv.z; t1 = (M->aabb_hi[2] - ray.o.z) * inv.z;
+    g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
+    const float mg = fmaxf(fabsf(g0), fabsf(g1)) * 2e-6f + 1e-30f;
+    const bool finite = big < 1e30f;  // a zero direction component makes a slab distance infinite
+    if (finite && g1 < g0 - mg) return false;
+    if (finite && g1 > g0 + mg) return true;
+    return aabb_gate_exact(M, ray);
+}
+
 // Nodelet fetch: the leading `lds_n` units of the kd array are resident in LDS.
-__device__ __forceinline__ uint4 kd_fetch(const uint4 *__restrict__ g, const uint4 *s, uint32_t lds_n, uint32_t i) {
-    return (i < lds_n) ? s[i] : g[i];
+__device__ __forceinline__ uint4 kd_fetch(gu4 g, const Ctx &cx, uint32_t i) {
+    uint4 r;
+    if (i < cx.lds_n) r = ld(cx.lds, i);
+    else r = ld(g, i);
+    return r;
 }
 
 // Closest triangle of one mesh with t >= 0 (KDTree.cpp:31-85 semantics: the caller applies
-// `t >= EPSILON && t < best`).  Stackless: locate the leaf that holds the entry point, test its
-// triangles, leave through the exit face's rope, repeat while no hit lies inside the visited cells.
-// Triangle rows: 0 {c0, id} 1 {e1, d00} 2 {e2, d01} 3 {n, D} 4 {d11, denom, -, -}.
-__device__ __forceinline__ bool mesh_closest(const DScene &S, const uint4 *s_units, const DMesh &M, const Ray &ray,
-                                             float &best_t, uint32_t &best_tri, float &bu, float &bv) {
-    if (!aabb_gate(M.aabb_lo, M.aabb_hi, ray)) return false;  // KDTree.cpp:82
-    const f3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+// `t >= EPSILON && t < best`); the ray has already passed mesh_gate.  Stackless: locate the leaf that
+// holds the entry point, test its triangles, leave through the exit face's rope, repeat while no hit lies
+// inside the visited cells.  Triangle rows: 0 {c0, id} 1 {e1, d00} 2 {e2, d01} 3 {n, D} 4 {d11, denom}.
+__device__ __forceinline__ bool mesh_traverse(const Ctx &cx, cmesh M, const Ray &ray, f3 inv, float &best_t,
+                                              uint32_t &best_tri, float &bu, float &bv) {
     float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
     {
-        float t0 = (M.kd_lo[0] - ray.o.x) * inv.x, t1 = (M.kd_hi[0] - ray.o.x) * inv.x;
+        float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
         t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
-        t0 = (M.kd_lo[1] - ray.o.y) * inv.y; t1 = (M.kd_hi[1] - ray.o.y) * inv.y;
+        t0 = (M->kd_lo[1] - ray.o.y) * inv.y; t1 = (M->kd_hi[1] - ray.o.y) * inv.y;
         t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
-        t0 = (M.kd_lo[2] - ray.o.z) * inv.z; t1 = (M.kd_hi[2] - ray.o.z) * inv.z;
+        t0 = (M->kd_lo[2] - ray.o.z) * inv.z; t1 = (M->kd_hi[2] - ray.o.z) * inv.z;
         t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
     }
-    if (!(t_entry <= t_scene_exit)) return false;
     best_t = HRT_FLT_MAX;
+    if (!(t_entry <= t_scene_exit)) return false;
     bool found = false;
-    uint32_t ref = M.root;
-    const uint4 *__restrict__ g_units = S.kd_units;
-    const float4 *__restrict__ tris = S.tris;
-    for (int guard = 0; guard < 2048 && ref != HRT_KD_NIL; ++guard) {  // every wave reaches the bound
-        const f3 p = ray.o + t_entry * ray.d;
-        while (!(ref & HRT_KD_LEAF)) {
-            const uint4 nd = kd_fetch(g_units, s_units, S.lds_units, ref);
-            const float split = __uint_as_float(nd.x);
-            const float pc = comp(p, nd.y), dc = comp(ray.d, nd.y);
-            const bool left = (pc < split) || (pc == split && dc < 0.f);
-            ref = left ? nd.z : nd.w;
-        }
-        const uint32_t lu = ref & ~HRT_KD_LEAF;
-        const uint4 l0 = kd_fetch(g_units, s_units, S.lds_units, lu);
-        const uint4 l1 = kd_fetch(g_units, s_units, S.lds_units, lu + 1);
-        const uint32_t first = M.tri_base + l0.w, count = l1.w;
-        for (uint32_t k = 0; k < count; ++k) {
-            const float4 *__restrict__ tr = tris + HRT_TRI_ROWS * (first + k);
-            const float4 r3 = tr[3];
-            const f3 n = mk(r3);
-            const float dotRN = dot(ray.d, n);
-            if (!(dotRN < 0.f)) continue;                       // Triangle.h:80-91: parallel or back-facing (NaN: no hit)
-            const float t = (r3.w - dot(ray.o, n)) / dotRN;     // :95
-            if (t < 0.f || !(t < best_t)) continue;             // :96, then the leaf's strict `<` (KDTree.cpp:44)
-            const float4 r0 = tr[0], r1 = tr[1], r2 = tr[2], r4 = tr[4];
-            const f3 v2 = (ray.o + t * ray.d) - mk(r0);
-            const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
-            const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;  // Triangle.h:72-74
-            const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
-            const float u0 = 1 - u1 - u2;
-            if (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1) {
-                best_t = t; best_tri = first + k; bu = u1; bv = u2; found = true;
+    gu4 g_units = (gu4)cx.S->kd_units;
+    gf4 tris = (gf4)cx.S->tris;
+    const uint32_t tri_base = M->tri_base;
+    // One flat loop, one small unit of work per lane per trip (descend <= 2 levels, then enter the leaf /
+    // test ONE triangle / leave through a rope): a trip costs the same for all lanes and the trip count is
+    // the largest number of units any lane needs.
+    uint32_t ref = M->root;
+    uint32_t k = 0, cnt = ~0u, first = 0;  // triangle cursor of the current leaf; cnt == ~0: leaf not entered yet
+    f3 p = ray.o + t_entry * ray.d;
+    for (int guard = 0; guard < 8192 && ref != HRT_KD_NIL; ++guard) {  // bounded: every wave leaves
+#pragma unroll
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            if (!(ref & HRT_KD_LEAF)) {
+                const uint4 nd = kd_fetch(g_units, cx, ref);
+                const float split = __uint_as_float(nd.x);
+                const float pc = comp(p, nd.y), dc = comp(ray.d, nd.y);
+                const bool left = (pc < split) || (pc == split && dc < 0.f);
+                ref = left ? nd.z : nd.w;
             }
         }
-        // exit face of this cell
-        const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
-        const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
-        const float ez = ((ray.d.z > 0.f ? __uint_as_float(l1.z) : __uint_as_float(l0.z)) - ray.o.z) * inv.z;
-        float t_exit = HRT_FLT_MAX;
-        uint32_t face = 6;
-        if (ray.d.x != 0.f && ex < t_exit) { t_exit = ex; face = ray.d.x > 0.f ? 1u : 0u; }
-        if (ray.d.y != 0.f && ey < t_exit) { t_exit = ey; face = ray.d.y > 0.f ? 3u : 2u; }
-        if (ray.d.z != 0.f && ez < t_exit) { t_exit = ez; face = ray.d.z > 0.f ? 5u : 4u; }
-        if (best_t <= t_exit || face == 6) break;
-        t_entry = fmaxf(t_entry, t_exit);
-        const uint4 rp = kd_fetch(g_units, s_units, S.lds_units, lu + 2 + (face >> 2));
-        const uint32_t sel = face & 3u;
-        ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
+        if (ref & HRT_KD_LEAF) {
+            const uint32_t lu = ref & ~HRT_KD_LEAF;
+            const uint4 l0 = kd_fetch(g_units, cx, lu);
+            const uint4 l1 = kd_fetch(g_units, cx, lu + 1);
+            if (cnt == ~0u) { first = tri_base + l0.w; cnt = l1.w; k = 0; }
+            if (k < cnt) {
+                gf4 tr = tris + HRT_TRI_ROWS * (first + k);
+                const float4 r3 = ld(tr, 3);
+                const f3 n = mk(r3);
+                const float dotRN = dot(ray.d, n);
+                if (dotRN < 0.f) {                                     // Triangle.h:80-91: else parallel / back-facing (NaN: no hit)
+                    const float t = (r3.w - dot(ray.o, n)) / dotRN;    // :95
+                    if (!(t < 0.f) && t < best_t) {                    // :96, then the leaf's strict `<` (KDTree.cpp:44)
+                        const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
+                        const f3 v2 = (ray.o + t * ray.d) - mk(r0);
+                        const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
+                        const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;  // Triangle.h:72-74
+                        const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
+                        const float u0 = 1 - u1 - u2;
+                        if (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1) {
+                            best_t = t; best_tri = first + k; bu = u1; bv = u2; found = true;
+                        }
+                    }
+                }
+                ++k;
+            }
+            if (k >= cnt) {  // leave the cell through its exit face
+                const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
+                const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
+                const float ez = ((ray.d.z > 0.f ? __uint_as_float(l1.z) : __uint_as_float(l0.z)) - ray.o.z) * inv.z;
+                float t_exit = HRT_FLT_MAX;
+                uint32_t face = 6;
+                if (ray.d.x != 0.f && ex < t_exit) { t_exit = ex; face = ray.d.x > 0.f ? 1u : 0u; }
+                if (ray.d.y != 0.f && ey < t_exit) { t_exit = ey; face = ray.d.y > 0.f ? 3u : 2u; }
+                if (ray.d.z != 0.f && ez < t_exit) { t_exit = ez; face = ray.d.z > 0.f ? 5u : 4u; }
+                if (best_t <= t_exit || face == 6) {
+                    ref = HRT_KD_NIL;  // the closest hit lies inside the cells already visited
+                } else {
+                    t_entry = fmaxf(t_entry, t_exit);
+                    p = ray.o + t_entry * ray.d;
+                    const uint4 rp = kd_fetch(g_units, cx, lu + 2 + (face >> 2));
+                    const uint32_t sel = face & 3u;
+                    ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
+                    cnt = ~0u;
+                }
+            }
+        }
     }
     return found;
 }
 
-// Scene::computeIntersection, Scene.h:202-230.
-__device__ __forceinline__ Hit closest_hit(const DScene &S, const uint4 *s_units, const Ray &ray) {
+__device__ __forceinline__ f3 ray_inv(const Ray &ray) {
+    return mk(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+}
+
+// Spheres then squares of Scene::computeIntersection (Scene.h:207-221).
+__device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
+    cscene S = cx.S;
     Hit h;
     h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
-    const float4 *__restrict__ sph = S.spheres;
-    for (uint32_t i = 0; i < S.n_spheres; ++i) {
+    cf4 sph = (cf4)S->spheres;
+    const uint32_t ns = S->n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) {
         float t;
-        if (sphere_t(sph[2 * i], sph[2 * i + 1], ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
+        if (sphere_t(ld(sph, 2 * i), ld(sph, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
     }
-    const float4 *__restrict__ qd = S.quads;
-    for (uint32_t i = 0; i < S.n_quads; ++i) {
-        float t, u, v;
-        if (quad_t(qd + HRT_QUAD_ROWS * i, ray, h.t, t, u, v)) { h.kind = 2; h.index = i; h.t = t; h.a0 = u; h.a1 = v; }
-    }
-    for (uint32_t i = 0; i < S.n_meshes; ++i) {
-        float t, u, v;
-        uint32_t tri;
-        if (mesh_closest(S, s_units, S.meshes[i], ray, t, tri, u, v) && t < h.t && HRT_T_ACCEPT(t)) {
-            h.kind = 3; h.index = i; h.t = t; h.tri = tri; h.a0 = u; h.a1 = v;
+    cf4 qd = (cf4)S->quads;
+    const uint32_t nq = S->n_quads;
+    if (nq <= 64u) {
+        // FILTER (wave-uniform loop, scalar rows, no division): an approximate t and inside test with
+        // conservative error margins decide which quads can possibly be the closest accepted hit.
+        // REFINE: only those (usually one per lane) go through the exact Square::intersect arithmetic,
+        // in index order with the reference's strict `<`, so the selected hit is the reference's.
+        uint64_t cand = 0ull;
+        float tsure = h.t;  // upper bound on the exact t of a hit that certainly exists
+        for (uint32_t i = 0; i < nq; ++i) {
+            const float4 q1 = ld(qd, HRT_QUAD_ROWS * i + 1);
+            const uint32_t flags = __float_as_uint(q1.w);
+            if (flags & HRT_QUAD_FLAG_MOVING) { cand |= 1ull << i; continue; }  // uniform branch; the exact path decides
+            const float4 q0 = ld(qd, HRT_QUAD_ROWS * i), q2 = ld(qd, HRT_QUAD_ROWS * i + 2), q3 = ld(qd, HRT_QUAD_ROWS * i + 3);
+            const f3 n = mk(q1);
+            const float dotRN = dot(ray.d, n);                    // exact: the sign tests are the reference's
+            const bool front = (flags & HRT_QUAD_FLAG_GLASS) ? (dotRN != 0.f) : (dotRN < 0.f);
+            const float num = q0.w - dot(ray.o, n);               // exact numerator
+            const float ta = num * __builtin_amdgcn_rcpf(dotRN);  // |ta - fl(num/dotRN)| <= 4e-7 |t|
+            const float ax = __builtin_fmaf(ta, ray.d.x, ray.o.x) - q0.x, ay = __builtin_fmaf(ta, ray.d.y, ray.o.y) - q0.y,
+                        az = __builtin_fmaf(ta, ray.d.z, ray.o.z) - q0.z;
+            const float x1 = __builtin_fmaf(az, q2.z, __builtin_fmaf(ay, q2.y, ax * q2.x));
+            const float x2 = __builtin_fmaf(az, q3.z, __builtin_fmaf(ay, q3.y, ax * q3.x));
+            const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);  // bound on |p' - p|, generous
+            const float m1 = q2.w * e, m2 = q3.w * e, s1 = q2.w * q2.w, s2 = q3.w * q3.w;
+            const bool loose = front && ta >= 9e-6f && ta * (1.f - 1e-6f) <= tsure && x1 >= -m1 && x1 <= s1 + m1 && x2 >= -m2 &&
+                               x2 <= s2 + m2;
+            const bool sure = front && ta >= 1.1e-5f && x1 >= m1 && x1 <= s1 - m1 && x2 >= m2 && x2 <= s2 - m2;
+            if (loose) cand |= 1ull << i;
+            if (sure) tsure = fminf(tsure, ta * (1.f + 1e-6f));
+        }
+        gf4 gq = (gf4)S->quads;
+        while (cand) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            float t, u, v;
+            if (quad_t(gq + HRT_QUAD_ROWS * i, ray, h.t, t, u, v)) { h.kind = 2; h.index = i; h.t = t; h.a0 = u; h.a1 = v; }
+        }
+    } else {
+        for (uint32_t i = 0; i < nq; ++i) {
+            float t, u, v;
+            if (quad_t(qd + HRT_QUAD_ROWS * i, ray, h.t, t, u, v)) { h.kind = 2; h.index = i; h.t = t; h.a0 = u; h.a1 = v; }
         }
     }
     return h;
 }
 
+// Which meshes' boxes the ray enters (bit i = mesh i; the first 32 meshes).
+__device__ __forceinline__ uint32_t mesh_gates(const Ctx &cx, const Ray &ray) {
+    const uint32_t nm = min(cx.S->n_meshes, 32u);
+    if (nm == 0) return 0u;
+    const f3 inv = ray_inv(ray);
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < nm; ++i)
+        if (mesh_gate((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
+    return m;
+}
+
+// The mesh loop of Scene::computeIntersection (Scene.h:222-228) over the meshes in `mask`.
+__device__ __forceinline__ void meshes_hit(const Ctx &cx, const Ray &ray, uint32_t mask, Hit &h) {
+    const f3 inv = ray_inv(ray);
+    const uint32_t nm = min(cx.S->n_meshes, 32u);
+    for (uint32_t i = 0; i < nm; ++i) {  // wave-uniform loop: scalar mesh records
+        if (mask & (1u << i)) {
+            float t, u, v;
+            uint32_t tri;
+            if (mesh_traverse(cx, (cmesh)cx.S->meshes + i, ray, inv, t, tri, u, v) && t < h.t && HRT_T_ACCEPT(t)) {
+                h.kind = 3; h.index = i; h.t = t; h.tri = tri; h.a0 = u; h.a1 = v;
+            }
+        }
+    }
+}
+
+// Scene::computeIntersection, Scene.h:202-230 (immediate form: AOV kernel).
+__device__ __forceinline__ Hit closest_hit(const Ctx &cx, const Ray &ray) {
+    Hit h = prims_hit(cx, ray);
+    const uint32_t m = mesh_gates(cx, ray);
+    if (m) meshes_hit(cx, ray, m, h);
+    return h;
+}
+
 // Scene::computeShadow, Scene.h:235-255: candidates in object order, each lets the ray
 // through with probability `transparency` (one draw per candidate).
-__device__ __forceinline__ bool shadow_blocked(const DScene &S, const uint4 *s_units, const Ray &ray, float tmax, Rng &rng) {
-    const float4 *__restrict__ sph = S.spheres;
-    const float4 *__restrict__ mats = S.materials;
-    for (uint32_t i = 0; i < S.n_spheres; ++i) {
+__device__ __forceinline__ bool shadow_blocked(const Ctx &cx, const Ray &ray, float tmax, Rng &rng) {
+    cscene S = cx.S;
+    cf4 sph = (cf4)S->spheres;
+    gf4 mats = (gf4)S->materials;
+    const uint32_t ns = S->n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) {
         float t;
-        const float4 r1 = sph[2 * i + 1];
-        if (sphere_t(sph[2 * i], r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
-            const float transparency = mats[HRT_MAT_ROWS * __float_as_uint(r1.w)].w;
+        const float4 r1 = ld(sph, 2 * i + 1);
+        if (sphere_t(ld(sph, 2 * i), r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
+            const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(r1.w)).w;
             if (rng.next() > transparency) return true;
         }
     }
-    const float4 *__restrict__ qd = S.quads;
-    for (uint32_t i = 0; i < S.n_quads; ++i) {
+    cf4 qd = (cf4)S->quads;
+    const uint32_t nq = S->n_quads;
+    for (uint32_t i = 0; i < nq; ++i) {
         float t, u, v;
         if (quad_t(qd + HRT_QUAD_ROWS * i, ray, tmax, t, u, v)) {
-            const float transparency = mats[HRT_MAT_ROWS * __float_as_uint(qd[HRT_QUAD_ROWS * i + 4].w)].w;
+            const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(ld(qd, HRT_QUAD_ROWS * i + 4).w)).w;
             if (rng.next() > transparency) return true;
         }
     }
-    for (uint32_t i = 0; i < S.n_meshes; ++i) {
-        float t, u, v;
-        uint32_t tri;
-        if (mesh_closest(S, s_units, S.meshes[i], ray, t, tri, u, v) && t < tmax && HRT_T_ACCEPT(t)) {
-            const float transparency = mats[HRT_MAT_ROWS * S.meshes[i].material].w;
-            if (rng.next() > transparency) return true;
+    const uint32_t nm = min(S->n_meshes, 32u);
+    if (nm) {
+        const f3 inv = ray_inv(ray);
+        for (uint32_t i = 0; i < nm; ++i) {
+            cmesh M = (cmesh)S->meshes + i;
+            float t, u, v;
+            uint32_t tri;
+            if (mesh_gate(M, ray, inv) && mesh_traverse(cx, M, ray, inv, t, tri, u, v) && t < tmax && HRT_T_ACCEPT(t)) {
+                const float transparency = ld(mats, HRT_MAT_ROWS * M->material).w;
+                if (rng.next() > transparency) return true;
+            }
         }
     }
     return false;
@@ -298,39 +450,42 @@ __device__ __forceinline__ bool shadow_blocked(const DScene &S, const uint4 *s_u
 // rows: 0 {albedo.xyz, transparency} 1 {index_medium, type, texture_type, emissive}
 //       2 {checker1.xyz, scale_x} 3 {checker2.xyz, scale_y} 4 {light_color.xyz, intensity}
 //       5 {image, normal_map, -, -}
-__device__ __forceinline__ uint32_t texel(const DScene &S, int img, float u, float v, float sx, float sy) {
-    const DImage im = S.images[img];
+__device__ __forceinline__ uint32_t texel(cscene S, int img, float u, float v, float sx, float sy) {
+    gimg im = (gimg)S->images + img;
+    const int iw = im->w, ih = im->h;
     float uu = u * sx, vv = v * sy;
     uu = uu - truncf(uu);            // (float)fmod((double)(u*sx), 1.): exact
     vv = 1.f - (vv - truncf(vv));    // (float)(1 - fmod(...)): one correctly rounded subtraction either way
-    const int x = (int)(uu * (float)(im.w - 1));
-    const int y = (int)(vv * (float)(im.h - 1));
-    return S.texels[im.offset + (uint32_t)(y * im.w + x)];
+    const int x = (int)(uu * (float)(iw - 1));
+    const int y = (int)(vv * (float)(ih - 1));
+    return ((gu1)S->texels)[im->offset + (uint32_t)(y * iw + x)];
 }
 __device__ __forceinline__ f3 unit_rgb(uint32_t px) {  // c/255. in double, narrowed (Material.cpp:87)
     return mk(c_u8_lut[px & 255u], c_u8_lut[(px >> 8) & 255u], c_u8_lut[(px >> 16) & 255u]);
 }
 
 // Material::texture, Material.cpp:63-92
-__device__ __forceinline__ f3 mat_texture(const DScene &S, const float4 *__restrict__ m, uint32_t tex_type, f3 color, float u, float v) {
+__device__ __forceinline__ f3 mat_texture(cscene S, gf4 m, uint32_t tex_type, f3 color, float u, float v) {
     if (tex_type == 1u) {
-        const float4 c1 = m[2], c2 = m[3];
+        const float4 c1 = ld(m, 2), c2 = ld(m, 3);
         color = ((int)(u * c1.w) % 2 == (int)(v * c2.w) % 2) ? mk(c1) : mk(c2);
     } else if (tex_type == 2u) {
-        const int img = (int)__float_as_uint(m[5].x);
-        if (img < 0 || S.images[img].w < 1 || S.images[img].h < 1) {
+        const int img = (int)__float_as_uint(ld(m, 5).x);
+        bool empty = img < 0;
+        if (!empty) { gimg im = (gimg)S->images + img; empty = im->w < 1 || im->h < 1; }
+        if (empty) {
             color = ((int)((double)u * 8.) % 2 == (int)((double)v * 8.) % 2) ? mk(0.f, 0.f, 0.f) : mk(1.f, 0.f, 1.f);
         } else {
-            color = unit_rgb(texel(S, img, u, v, m[2].w, m[3].w));
+            color = unit_rgb(texel(S, img, u, v, ld(m, 2).w, ld(m, 3).w));
         }
     }
     return color;
 }
 
 // Material::emit, Material.cpp:13-24
-__device__ __forceinline__ f3 mat_emit(const DScene &S, const float4 *__restrict__ m, uint32_t tex_type, bool emissive, float u, float v) {
+__device__ __forceinline__ f3 mat_emit(cscene S, gf4 m, uint32_t tex_type, bool emissive, float u, float v) {
     if (!emissive) return mk(0.f, 0.f, 0.f);
-    const float4 lc = m[4];
+    const float4 lc = ld(m, 4);
     f3 c = mk(0.f, 0.f, 0.f);
     if (tex_type == 0u) c = mk(lc);
     else c = mat_texture(S, m, tex_type, c, u, v);
@@ -344,18 +499,19 @@ struct Surface {
 };
 
 // The hit-dependent part of Scene::rayTraceRecursive, Scene.h:270-300.
-__device__ __forceinline__ Surface shade(const DScene &S, const Ray &ray, const Hit &h) {
+__device__ __forceinline__ Surface shade(cscene S, const Ray &ray, const Hit &h) {
     Surface sf;
-    const float4 *__restrict__ mats = S.materials;
+    gf4 mats = (gf4)S->materials;
     const f3 p = ray.o + h.t * ray.d;
     sf.p = p;
     sf.emission = mk(0.f, 0.f, 0.f);
     uint32_t mat_id;
     if (h.kind == 1u) {
-        const float4 r0 = S.spheres[2 * h.index], r1 = S.spheres[2 * h.index + 1];
+        gf4 sp = (gf4)S->spheres;
+        const float4 r0 = ld(sp, 2 * h.index), r1 = ld(sp, 2 * h.index + 1);
         mat_id = __float_as_uint(r1.w);
-        const float4 *m = mats + HRT_MAT_ROWS * mat_id;
-        const float4 m0 = m[0], m1 = m[1];
+        gf4 m = mats + HRT_MAT_ROWS * mat_id;
+        const float4 m0 = ld(m, 0), m1 = ld(m, 1);
         const uint32_t tex_type = __float_as_uint(m1.z);
         const bool emissive = __float_as_uint(m1.w) != 0u;
         const f3 c = mk(r0) + ray.time * mk(r1);
@@ -370,41 +526,44 @@ __device__ __forceinline__ Surface shade(const DScene &S, const Ray &ray, const 
             sf.emission = mat_emit(S, m, tex_type, emissive, u, v);
         }
     } else if (h.kind == 2u) {
-        const float4 *q = S.quads + HRT_QUAD_ROWS * h.index;
-        mat_id = __float_as_uint(q[4].w);
-        const float4 *m = mats + HRT_MAT_ROWS * mat_id;
-        const float4 m0 = m[0], m1 = m[1];
+        gf4 q = (gf4)S->quads + HRT_QUAD_ROWS * h.index;
+        mat_id = __float_as_uint(ld(q, 4).w);
+        gf4 m = mats + HRT_MAT_ROWS * mat_id;
+        const float4 m0 = ld(m, 0), m1 = ld(m, 1);
         const uint32_t tex_type = __float_as_uint(m1.z);
         const bool emissive = __float_as_uint(m1.w) != 0u;
-        sf.n = mk(q[1]);
+        sf.n = mk(ld(q, 1));
         sf.albedo = mat_texture(S, m, tex_type, mk(m0), h.a0, h.a1);
-        const int nmap = (int)__float_as_uint(m[5].y);
+        const int nmap = (int)__float_as_uint(ld(m, 5).y);
         if (nmap >= 0) {  // Material::get_normal, Material.cpp:114-130
-            const uint32_t px = texel(S, nmap, h.a0, h.a1, m[2].w, m[3].w);
+            const uint32_t px = texel(S, nmap, h.a0, h.a1, ld(m, 2).w, ld(m, 3).w);
             const float nx = c_u8_lut[256u + (px & 255u)], ny = c_u8_lut[256u + ((px >> 8) & 255u)],
                         nz = c_u8_lut[256u + ((px >> 16) & 255u)];
-            sf.n = normalize(nx * mk(q[5]) + ny * mk(q[6]) + nz * sf.n);
+            sf.n = normalize(nx * mk(ld(q, 5)) + ny * mk(ld(q, 6)) + nz * sf.n);
         }
         sf.emission = mat_emit(S, m, tex_type, emissive, h.a0, h.a1);
     } else {
-        const DMesh &M = S.meshes[h.index];
-        mat_id = M.material;
-        const float4 m0 = mats[HRT_MAT_ROWS * mat_id];
-        const float4 r0 = S.tris[HRT_TRI_ROWS * h.tri], r3 = S.tris[HRT_TRI_ROWS * h.tri + 3];
+        cmesh M = (cmesh)S->meshes + h.index;  // per-lane index: the compiler falls back to vector loads
+        mat_id = M->material;
+        const float4 m0 = ld(mats, HRT_MAT_ROWS * mat_id);
+        gf4 tr = (gf4)S->tris + HRT_TRI_ROWS * h.tri;
+        const float4 r0 = ld(tr, 0), r3 = ld(tr, 3);
         sf.n = mk(r3);  // Triangle.h:32-37 flat normal, folded on the host
         sf.albedo = mk(m0);
         const uint32_t tid = __float_as_uint(r0.w);
-        if (M.color_type == 1) {
-            sf.albedo = mk(S.colors[M.color_base + tid]);
-        } else if (M.color_type == 0) {
-            const uint4 vi = S.tri_vids[M.color_base + tid];
+        const int ct = M->color_type;
+        gf4 colors = (gf4)S->colors;
+        if (ct == 1) {
+            sf.albedo = mk(ld(colors, M->color_base + tid));
+        } else if (ct == 0) {
+            const uint4 vi = ld((gu4)S->tri_vids, M->color_base + tid);
+            const uint32_t vb = M->vcolor_base;
             const float w1 = h.a0, w2 = h.a1, w0 = 1 - w1 - w2;
-            sf.albedo = w0 * mk(S.colors[M.vcolor_base + vi.x]) + w1 * mk(S.colors[M.vcolor_base + vi.y]) +
-                        w2 * mk(S.colors[M.vcolor_base + vi.z]);
+            sf.albedo = w0 * mk(ld(colors, vb + vi.x)) + w1 * mk(ld(colors, vb + vi.y)) + w2 * mk(ld(colors, vb + vi.z));
         }
     }
-    const float4 *m = mats + HRT_MAT_ROWS * mat_id;
-    const float4 m0 = m[0], m1 = m[1];
+    gf4 m = mats + HRT_MAT_ROWS * mat_id;
+    const float4 m0 = ld(m, 0), m1 = ld(m, 1);
     sf.transparency = m0.w;
     sf.index_medium = m1.x;
     sf.type = __float_as_uint(m1.y);
@@ -449,31 +608,34 @@ __device__ __forceinline__ void scatter(const Surface &sf, Ray &ray, Rng &rng) {
 }
 
 // Scene::skyboxTexture, Scene.h:149-161
-__device__ __forceinline__ f3 sky(const DScene &S, f3 dir, int remaining) {
-    if (S.skybox_image < 0) {
-        if (S.dark_sky) return mk(0.f, 0.f, 0.f);
+__device__ __forceinline__ f3 sky(cscene S, f3 dir, int remaining) {
+    const int sb = S->skybox_image;
+    if (sb < 0) {
+        if (S->dark_sky) return mk(0.f, 0.f, 0.f);
         const float a = (float)(0.5 * ((double)dir.y + 1.0));
         return (float)(1.0 - (double)a) * mk(1.f, 1.f, 1.f) + (a * mk(0.5f, 0.7f, 1.0f)) * (float)(remaining + 1);
     }
-    const DImage im = S.images[S.skybox_image];
+    gimg im = (gimg)S->images + sb;
+    const int iw = im->w, ih = im->h;
     const float u = (float)(0.5 + atan2((double)dir.z, (double)dir.x) / (2 * 3.14159265358979323846));
     const float v = (float)(0.5 - asin((double)dir.y) / 3.14159265358979323846);
-    int x = (int)(u * (float)im.w), y = (int)(v * (float)im.h);
-    x = min(x, im.w - 1);  // the reference reads out of bounds at u == 1; clamped (as the oracle)
-    y = min(y, im.h - 1);
-    return unit_rgb(S.texels[im.offset + (uint32_t)(y * im.w + x)]) * (float)remaining;
+    int x = (int)(u * (float)iw), y = (int)(v * (float)ih);
+    x = min(x, iw - 1);  // the reference reads out of bounds at u == 1; clamped (as the oracle)
+    y = min(y, ih - 1);
+    return unit_rgb(((gu1)S->texels)[im->offset + (uint32_t)(y * iw + x)]) * (float)remaining;
 }
 
 // Direct light with soft shadows, Scene.h:305-334.
-__device__ __forceinline__ f3 direct_light(const DScene &S, const uint4 *s_units, const Surface &sf, const Ray &ray, Rng &rng) {
+__device__ __forceinline__ f3 direct_light(const Ctx &cx, const Surface &sf, const Ray &ray, Rng &rng) {
     f3 color = mk(0.f, 0.f, 0.f);
-    const float4 *__restrict__ L = S.lights;
-    for (uint32_t i = 0; i < S.n_lights; ++i) {
-        const float4 l0 = L[2 * i];
+    cf4 L = (cf4)cx.S->lights;
+    const uint32_t nl = cx.S->n_lights;
+    for (uint32_t i = 0; i < nl; ++i) {
+        const float4 l0 = ld(L, 2 * i);
         const f3 lpos = mk(l0);
         const f3 Ld = normalize(lpos - sf.p);
         const float dotLN = dot(Ld, sf.n);
-        color = color + ((mk(L[1]) * sf.albedo) * fmaxf(0.0f, dotLN)) * (float)(1. - (double)sf.transparency);  // lights[0] (N2)
+        color = color + ((mk(ld(L, 1)) * sf.albedo) * fmaxf(0.0f, dotLN)) * (float)(1. - (double)sf.transparency);  // lights[0] (N2)
         int blocked = 0;
         const float delta = l0.w / 2.f;
         for (int j = 0; j < 10; ++j) {  // NB_ECH
@@ -485,7 +647,7 @@ __device__ __forceinline__ f3 direct_light(const DScene &S, const uint4 *s_units
             sr.o = sf.p + Ls * HRT_EPS;
             sr.d = normalize(Ls);
             sr.time = ray.time;
-            if (shadow_blocked(S, s_units, sr, tLight, rng)) blocked++;
+            if (shadow_blocked(cx, sr, tLight, rng)) blocked++;
         }
         const float shadow = (float)(1. - (double)((float)blocked / 10.f));
         color = color * shadow;  // the running sum, earlier lights included (N3)
@@ -494,19 +656,20 @@ __device__ __forceinline__ f3 direct_light(const DScene &S, const uint4 *s_units
 }
 
 // matrixUtilities.h:53-74 with the two inverse matrices supplied by the host (fp64, column-major).
-__device__ __forceinline__ void mult4(const double *__restrict__ m, double x, double y, double z, double w, double *r) {
+template <class M>
+__device__ __forceinline__ void mult4(M m, double x, double y, double z, double w, double *r) {
     r[0] = m[0] * x + m[4] * y + m[8] * z + m[12] * w;
     r[1] = m[1] * x + m[5] * y + m[9] * z + m[13] * w;
     r[2] = m[2] * x + m[6] * y + m[10] * z + m[14] * w;
     r[3] = m[3] * x + m[7] * y + m[11] * z + m[15] * w;
 }
-__device__ __forceinline__ Ray camera_ray(const DCamera &C, float u, float v, float time) {
+__device__ __forceinline__ Ray camera_ray(ccam C, float u, float v, float time) {
     double ri[4], r[4];
-    mult4(C.p_inv, 2.0 * (double)u - 1.0, -(2.0 * (double)v - 1.0), 0.0, 1.0, ri);
-    mult4(C.mv_inv, ri[0], ri[1], ri[2], ri[3], r);
+    mult4(C->p_inv, 2.0 * (double)u - 1.0, -(2.0 * (double)v - 1.0), 0.0, 1.0, ri);
+    mult4(C->mv_inv, ri[0], ri[1], ri[2], ri[3], r);
     const f3 world = mk((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]));
     Ray out;
-    out.o = mk(C.eye);
+    out.o = mk(C->eye[0], C->eye[1], C->eye[2]);
     // normalised twice, as the reference does: once in screen_space_to_world_space_ray
     // (matrixUtilities.h:73) and again by the Ray constructor (main.cpp:192, Line.h:15)
     out.d = normalize(normalize(world - out.o));
@@ -514,18 +677,25 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &C, float u, float v, fl
     return out;
 }
 
-}  // namespace hrtk
-
-using namespace hrtk;
-
 // ---------------------------------------------------------------------------
-// The megakernel.  256 threads = 4 waves per workgroup; grid = resident workgroups only.
+// The megakernel body.  LIGHTS = the scene has point lights (soft-shadow fan-out, Scene.h:305-334,
+// compiled in); scenes without lights run the variant that carries none of that code or its registers.
 // ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256) hrt_trace_kernel(const DRender R) {
+template <bool LIGHTS>
+__device__ __forceinline__ void trace_body(const DRender &R) {
     extern __shared__ uint4 s_units[];
-    const DScene &S = R.scene;
-    for (uint32_t i = threadIdx.x; i < S.lds_units; i += blockDim.x) s_units[i] = S.kd_units[i];
+    Ctx cx;
+    cx.S = (cscene)R.scene;
+    cx.lds = (lu4)s_units;
+    cx.lds_n = R.lds_units;
+    cx.err_abs = R.err_abs;
+    ccam cam = (ccam)R.cam;
+    {
+        gu4 g_units = (gu4)cx.S->kd_units;
+        for (uint32_t i = threadIdx.x; i < cx.lds_n; i += blockDim.x) s_units[i] = ld(g_units, i);
+    }
     __syncthreads();
+    const bool has_mesh = cx.S->n_meshes != 0u;
 
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
@@ -547,29 +717,50 @@ extern "C" __global__ void __launch_bounds__(256) hrt_trace_kernel(const DRender
         f3 thr = mk(1.f, 1.f, 1.f), rad = mk(0.f, 0.f, 0.f);
         Rng rng;
         rng.k0 = rng.k1 = rng.i = 0;
+        Hit h;
+        h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
+        uint32_t parked = 0;     // meshes whose box this lane's ray enters and that are still to be walked
+        uint32_t stage = 0;      // 0: needs stage A   1: parked for stage B   2: ready for stage C
         bool live = inside && R.spp > 0;
 
         while (__ballot(live) != 0ull) {
-            if (live) {
-                if (remaining == 0) {  // regenerate: next camera sample of this pixel (main.cpp:188-192)
+            // ---- stage A: (re)generate, spheres + squares, mesh gates
+            if (live && stage == 0u) {
+                if (remaining == 0) {  // next camera sample of this pixel (main.cpp:188-192)
                     rng.start(R.seed_lo, R.seed_hi, pixel, s);
                     const float u = ((float)px + rng.next()) / (float)R.w;
                     const float v = ((float)py + rng.next()) / (float)R.h;
                     const float tm = rng.next();
-                    ray = camera_ray(R.cam, u, v, tm);
+                    ray = camera_ray(cam, u, v, tm);
                     thr = mk(1.f, 1.f, 1.f);
                     rad = mk(0.f, 0.f, 0.f);
                     remaining = 6;  // MAXBOUNCES
                 }
-                const Hit h = closest_hit(S, s_units, ray);
+                h = prims_hit(cx, ray);
+                parked = has_mesh ? mesh_gates(cx, ray) : 0u;
+                stage = parked ? 1u : 2u;
+            }
+            // ---- stage B: walk the meshes for the parked lanes once enough of them have gathered
+            if (has_mesh) {
+                const uint64_t waiting = __ballot(live && stage == 1u);
+                const uint64_t ready = __ballot(live && stage == 2u);
+                if (waiting != 0ull && (__popcll(waiting) >= HRT_MESH_BATCH || ready == 0ull)) {
+                    if (live && stage == 1u) {
+                        meshes_hit(cx, ray, parked, h);
+                        stage = 2u;
+                    }
+                }
+            }
+            // ---- stage C: shade, scatter, end of path
+            if (live && stage == 2u) {
                 bool ended;
                 if (h.kind == 0u) {
-                    rad = rad + thr * sky(S, ray.d, remaining);
+                    rad = rad + thr * sky(cx.S, ray.d, remaining);
                     ended = true;
                 } else {
-                    const Surface sf = shade(S, ray, h);
+                    const Surface sf = shade(cx.S, ray, h);
                     f3 direct = mk(0.f, 0.f, 0.f);
-                    if (S.n_lights) direct = direct_light(S, s_units, sf, ray, rng);
+                    if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
                     rad = rad + thr * (direct + sf.emission);
                     thr = thr * sf.albedo;
                     scatter(sf, ray, rng);
@@ -582,6 +773,7 @@ extern "C" __global__ void __launch_bounds__(256) hrt_trace_kernel(const DRender
                     ++s;
                     live = s < R.spp;
                 }
+                stage = 0u;
             }
         }
         float *o = R.out_tiles + ((size_t)j * 64u + lane) * 3u;
@@ -589,11 +781,23 @@ extern "C" __global__ void __launch_bounds__(256) hrt_trace_kernel(const DRender
         if (inside) {
             const float nspp = (float)R.spp;
             c = mk(sum.x / nspp, sum.y / nspp, sum.z / nspp);  // main.cpp:195
-            if (R.flags & 1u)  // gamma_correct, Functions.cpp:56-60: pow in double
-                c = mk((float)pow((double)c.x, 1.0 / 2.2), (float)pow((double)c.y, 1.0 / 2.2), (float)pow((double)c.z, 1.0 / 2.2));
         }
         o[0] = c.x; o[1] = c.y; o[2] = c.z;
     }
+}
+
+}  // namespace hrtk
+
+using namespace hrtk;
+
+extern "C" __global__ void __launch_bounds__(256, HRT_MIN_WAVES) hrt_trace_kernel(const DRender R) { trace_body<false>(R); }
+extern "C" __global__ void __launch_bounds__(256, HRT_MIN_WAVES) hrt_trace_kernel_lights(const DRender R) { trace_body<true>(R); }
+
+// gamma_correct (Functions.cpp:56-60): pow(c, 1/2.2) in double, over this rank's tile buffer.  Kept out of
+// the megakernel: fp64 pow is register-hungry and runs once per pixel.
+extern "C" __global__ void hrt_gamma_kernel(float *__restrict__ v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (float)pow((double)v[i], 1.0 / 2.2);
 }
 
 // Tile-major per-rank blocks -> row-major frame (rank 0, after the gather).
@@ -617,18 +821,21 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.w * R.h) return;
     const uint32_t x = idx % R.w, y = idx / R.w;
-    DScene S = R.scene;
-    S.lds_units = 0;  // every nodelet from global memory here
-    const Ray ray = camera_ray(R.cam, ((float)x + 0.5f) / (float)R.w, ((float)y + 0.5f) / (float)R.h, 0.f);
-    const Hit h = closest_hit(S, nullptr, ray);
+    Ctx cx;
+    cx.S = (cscene)R.scene;
+    cx.lds = (lu4) nullptr;
+    cx.lds_n = 0;  // every nodelet from global memory here
+    cx.err_abs = R.err_abs;
+    const Ray ray = camera_ray((ccam)R.cam, ((float)x + 0.5f) / (float)R.w, ((float)y + 0.5f) / (float)R.h, 0.f);
+    const Hit h = closest_hit(cx, ray);
     f3 o = mk(0.f, 0.f, 0.f);
     if (which == 0u) {
         float id = -1.f;
-        if (h.kind == 3u) id = (float)__float_as_uint(S.tris[HRT_TRI_ROWS * h.tri].w);
+        if (h.kind == 3u) id = (float)__float_as_uint(ld((gf4)cx.S->tris, HRT_TRI_ROWS * h.tri).w);
         else if (h.kind) id = (float)h.index;
         o = mk(h.kind ? h.t : 0.f, (float)h.kind, id);
     } else if (h.kind) {
-        const Surface sf = shade(S, ray, h);
+        const Surface sf = shade(cx.S, ray, h);
         o = which == 1u ? sf.n : (which == 2u ? sf.albedo : sf.emission);
     }
     out[3 * (size_t)idx] = o.x; out[3 * (size_t)idx + 1] = o.y; out[3 * (size_t)idx + 2] = o.z;
