@@ -167,6 +167,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
             return fail(HRT_ERR_INVALID, "quad material out of range");
     if (D.skybox_image >= (int32_t)D.n_images) return fail(HRT_ERR_INVALID, "skybox image out of range");
     if (D.n_lights && !D.lights) return fail(HRT_ERR_INVALID, "lights missing");
+    if (D.n_meshes > 32u) return fail(HRT_ERR_INVALID, "more than 32 meshes in one scene (the parked-mesh mask is 32 bits)");
 
     // ---- scene extent: an upper bound on |point| for every point a ray can start from or hit
     {

@@ -71,7 +71,7 @@ def main():
 
     imgs = {}
     for name, (w, h, spp) in {"cornell_box": (64, 64, 4), "cornell_mesh": (64, 36, 4), "random_spheres": (64, 36, 4),
-                              "mesh_in_box": (64, 36, 4)}.items():
+                              "mesh_in_box": (64, 36, 4), "backrooms_pool": (64, 36, 4)}.items():
         host = hrt.HostScene().setup(name, w / h, 1); desc = host.flatten(); cam = hrt.default_camera(w / h)
         sc = O.OracleScene(desc)
         imgs[name + "_render"] = sc.render(cam, w, h, spp, seed=1, threads=0)

@@ -68,6 +68,8 @@ def test_config_scenes_have_the_reference_object_counts(hrt):
     assert (c["spheres"], c["quads"], c["meshes"], c["lights"], c["dark_sky"]) == (82, 1, 0, 1, 0)  # Scene.h:829-924
     c = counts(hrt.HostScene().setup("mesh_in_box", 16 / 9, 1).flatten())
     assert (c["spheres"], c["quads"], c["meshes"]) == (0, 11, 1)
+    c = counts(hrt.HostScene().setup("backrooms_pool", 16 / 9, 1).flatten())
+    assert (c["spheres"], c["quads"], c["meshes"], c["lights"], c["dark_sky"]) == (2, 28, 3, 0, 1)  # Scene.h:1329-1882
 
 
 def test_error_behaviour_of_the_host_layer(hrt, tmp_path):

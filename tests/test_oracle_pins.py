@@ -92,7 +92,7 @@ def test_live_reference_parts_when_present(oracle):
 def test_oracle_renders_match_committed_images(hrt, oracle):
     """The oracle on this machine reproduces the committed oracle pixels (same compiler flags, no FMA)."""
     g = np.load(os.path.join(GOLDEN, "oracle_images.npz"))
-    for name in ["cornell_box", "cornell_mesh", "random_spheres", "mesh_in_box"]:
+    for name in ["cornell_box", "cornell_mesh", "random_spheres", "mesh_in_box", "backrooms_pool"]:
         w, h, spp, seed = (int(x) for x in g[name + "_shape"])
         host = hrt.HostScene().setup(name, w / h, 1)
         desc = host.flatten()

@@ -15,7 +15,7 @@ SAMPLE = (240, 135, 16)
 out = {"_sample": {"w": SAMPLE[0], "h": SAMPLE[1], "spp": SAMPLE[2], "seed": 1,
                    "record_bytes": {"sphere_test": 32, "quad_test": 48, "node_visit": 32, "tri_test": 40,
                                     "material_fetch": 64, "texel": 3, "framebuffer_per_pixel": 12}}}
-for name in ["cornell_box", "cornell_mesh", "random_spheres", "mesh_in_box"]:
+for name in ["cornell_box", "cornell_mesh", "random_spheres", "mesh_in_box", "backrooms_pool"]:
     w, h, spp = SAMPLE
     host = hrt.HostScene().setup(name, 16 / 9, 1)
     desc = host.flatten()
@@ -29,7 +29,7 @@ for name in ["cornell_box", "cornell_mesh", "random_spheres", "mesh_in_box"]:
     entry["algorithmic_bytes_per_sample"] = round(
         32 * ps["sphere_tests"] + 48 * ps["quad_tests"] + 32 * ps["node_visits"] + 40 * ps["tri_tests"]
         + 64 * ps["shaded_hits"] + 3 * ps["texel_lookups"], 1)
-    if desc and name in ("cornell_mesh", "mesh_in_box"):
+    if name in ("cornell_mesh", "mesh_in_box", "backrooms_pool"):
         entry["kd_tree"] = host.kd_stats(0)
     out[name] = entry
     print(name, entry)
