@@ -65,9 +65,11 @@ def cpu_baseline(hrt, desc, cam):
     threads = os.cpu_count() or 1
     scene = oracle_lib.OracleScene(desc, oracle_lib.MESH_REF_TREE)
     t0 = time.perf_counter()
-    scene.render(cam, w, h, 4, seed=SEED, threads=threads)  # calibration (also pages the scene in)
-    rate = w * h * 4 / max(time.perf_counter() - t0, 1e-3)
-    spp = int(min(1024, max(8, 15.0 * rate / (w * h))))
+    scene.render(cam, w, h, 2, seed=SEED, threads=threads)  # page the scene in, start the thread pool once
+    t0 = time.perf_counter()
+    scene.render(cam, w, h, 32, seed=SEED, threads=threads)  # calibration
+    rate = w * h * 32 / max(time.perf_counter() - t0, 1e-3)
+    spp = int(min(1024, max(8, 12.0 * rate / (w * h))))
     t0 = time.perf_counter()
     scene.render(cam, w, h, spp, seed=SEED, threads=threads)
     dt = time.perf_counter() - t0
