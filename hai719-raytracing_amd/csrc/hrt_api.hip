@@ -2,6 +2,7 @@
 // gfx950 only.  No CPU fallback: every entry point that needs the GPU fails
 // with HRT_ERR_DEVICE when HIP cannot provide one.
 #include "hrt_kernels.hip"
+#include "hrt_stream.hip"
 
 #include <chrono>
 #include <cmath>
@@ -31,6 +32,7 @@ struct Runtime {
     int cus = 0;
     int blocks_per_cu = 0;
     uint32_t lds_budget = 0;  // bytes of dynamic LDS per workgroup for nodelets
+    bool use_stream = false;  // workgroup-streaming kernel (hrt_stream.hip), opt-in with HRT_KERNEL=stream
     hipFuncAttributes attr{};
 } g_rt;
 
@@ -54,6 +56,10 @@ float h_dot(H3 a, H3 b) {
 float h_msub(float a, float b, float c, float d) {  // a*b - c*d, each product rounded first
 #pragma clang fp contract(off)
     return a * b - c * d;
+}
+double h_mul64(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
 }
 float h_len(H3 a) { return (float)std::sqrt((double)h_dot(a, a)); }
 H3 h_normalize(H3 a) {
@@ -81,13 +87,16 @@ struct hrt_scene {
     uint32_t lds_units = 0;
     std::vector<void *> allocations;
     uint32_t *tile_counter = nullptr;
+    unsigned long long *stamps = nullptr;  // diagnostic cycle counters (HRT_STAMPS builds)
+    float *sp_scratch = nullptr;           // per-workgroup sample scratch of the streaming kernel
+    size_t sp_scratch_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     float bound = 0.f;  // largest distance of any scene point from the origin (filter margins)
     // scratch of hrt_render (whole frame on one GPU)
     float *d_tiles = nullptr, *d_frame = nullptr;
     size_t tiles_cap = 0, frame_cap = 0;
-    uint32_t last_grid = 0;
+    uint32_t last_grid = 0, last_waves = 0, last_lds = 0;
 };
 
 extern "C" {
@@ -128,6 +137,13 @@ int hrt_init(int device_ordinal) {
         for (int c = 0; c < 256; ++c) { lut[c] = (float)(c / 255.); lut[256 + c] = (float)(c / 127.5 - 1.); }
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof(lut)));
     }
+    {   // the streaming kernel keeps its path pool in LDS: 113 KiB + nodelets, one 1024-thread workgroup per CU
+        const int max_lds = 160 * 1024;
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        const char *k = std::getenv("HRT_KERNEL");
+        g_rt.use_stream = (k && std::string(k) == "stream");  // opt-in until it beats the lane-per-pixel kernel
+    }
     g_rt.ready = true;
     return HRT_OK;
 }
@@ -138,6 +154,8 @@ void hrt_scene_destroy(hrt_scene *s) {
     if (!s) return;
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->tile_counter) (void)hipFree(s->tile_counter);
+    if (s->stamps) (void)hipFree(s->stamps);
+    if (s->sp_scratch) (void)hipFree(s->sp_scratch);
     if (s->d_scene) (void)hipFree(s->d_scene);
     if (s->d_cam) (void)hipFree(s->d_cam);
     if (s->d_tiles) (void)hipFree(s->d_tiles);
@@ -392,6 +410,8 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     d.dark_sky = D.dark_sky;
     d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
     HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&s->stamps, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->stamps, 0, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     HIP_TRY(hipMalloc((void **)&s->d_scene, sizeof(DScene)));
@@ -445,7 +465,7 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
     // in closed form, fp64, column-major: modelview = [right; up; -forward] * translate(-eye),
     // projection = gluPerspective(fovy, aspect, znear, zfar) (Camera.cpp:41-50).
     {
-        double *mi = C.mv_inv, *pi = C.p_inv;
+        double mi[16], pi[16];
         for (int k = 0; k < 16; ++k) { mi[k] = 0.0; pi[k] = 0.0; }
         for (int r = 0; r < 3; ++r) {
             mi[0 + r] = (double)cam->right[r];
@@ -461,6 +481,13 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
         const double pc = -((double)cam->zfar + (double)cam->znear) / dz, pd = -2.0 * (double)cam->znear * (double)cam->zfar / dz;
         pi[0] = 1.0 / pa; pi[5] = 1.0 / pb; pi[11] = 1.0 / pd; pi[14] = -1.0; pi[15] = pc / pd;
         for (int a = 0; a < 3; ++a) C.eye[a] = (float)(mi[12 + a] / mi[15]);
+        C.pi0 = pi[0]; C.pi5 = pi[5]; C.pi15 = pi[15]; C.inv15 = 1.0 / pi[15];
+        for (int k = 0; k < 3; ++k) {
+            C.mx[k] = mi[k];
+            C.my[k] = mi[4 + k];
+            C.c1[k] = mi[8 + k] * -1.0;
+            C.c2[k] = h_mul64(mi[12 + k], pi[15]);
+        }
     }
     if (!s->cam_valid || std::memcmp(&C, &s->h_cam, sizeof(C)) != 0) {
         // the previous launch may still be reading the old block: stream order makes the copy wait for it
@@ -476,6 +503,7 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
     R.tiles_total = hrt_tiles_total(w, h);
     R.tiles_owned = hrt_tiles_owned(w, h, rank, world);
     R.tile_counter = s->tile_counter;
+    R.stamps = s->stamps;
     return HRT_OK;
 }
 
@@ -488,19 +516,46 @@ int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h
     R.out_tiles = d_tiles;
     hipStream_t stream = (hipStream_t)stream_;
     if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
-    const uint32_t lds_bytes = R.lds_units * 16u;
-    int per_cu = 0;
-    const void *kfn = s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    uint32_t grid = (uint32_t)(per_cu * g_rt.cus);
-    const uint32_t need = (R.tiles_owned + 3u) / 4u;  // 4 waves per workgroup, one tile per wave at a time
-    if (grid > need) grid = need;
+    const bool stream_kernel = g_rt.use_stream && !(flags & HRT_FLAG_WAVE_KERNEL);
+    uint32_t grid, lds_bytes;
+    if (stream_kernel) {
+        const uint32_t fixed = (uint32_t)(SP_FIELDS * HRT_SP_POOL * 4 + 8 * HRT_SP_POOL * 2 + sizeof(SpCtl) + 256 * 4);
+        const uint32_t room = (160u * 1024u - fixed) / 16u;
+        if (!(flags & HRT_FLAG_NO_LDS_TREE)) R.lds_units = std::min<uint32_t>(s->d.n_kd_units, room);
+        lds_bytes = fixed + R.lds_units * 16u;
+        grid = std::min<uint32_t>((uint32_t)g_rt.cus, R.tiles_owned);  // one workgroup per CU
+        const size_t need_floats = (size_t)grid * 64u * HRT_SP_SCHUNK * 3u;
+        if (s->sp_scratch_cap < need_floats) {
+            if (s->sp_scratch) (void)hipFree(s->sp_scratch);
+            s->sp_scratch = nullptr; s->sp_scratch_cap = 0;
+            HIP_TRY(hipMalloc((void **)&s->sp_scratch, need_floats * sizeof(float)));
+            s->sp_scratch_cap = need_floats;
+        }
+        R.sp_scratch = s->sp_scratch;
+    } else {
+        lds_bytes = R.lds_units * 16u;
+        int per_cu = 0;
+        const void *kfn = s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds_bytes));
+        if (per_cu < 1) per_cu = 1;
+        grid = (uint32_t)(per_cu * g_rt.cus);
+        const uint32_t need = (R.tiles_owned + 3u) / 4u;  // 4 waves per workgroup, one tile per wave at a time
+        if (grid > need) grid = need;
+        R.sp_scratch = nullptr;
+    }
     s->last_grid = grid;
+    s->last_lds = lds_bytes;
+    s->last_waves = stream_kernel ? grid * (HRT_SP_WG / 64) : grid * 4u;
     HIP_TRY(hipMemsetAsync(s->tile_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(s->stamps, 0, 16 * sizeof(unsigned long long), stream));  // [15] = give-up code of the streaming kernel
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace_kernel_lights, dim3(grid), dim3(256), lds_bytes, stream, R);
-    else hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(256), lds_bytes, stream, R);
+    if (stream_kernel) {
+        if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+        else hipLaunchKernelGGL(hrt_wgstream_kernel, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+    } else {
+        if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace_kernel_lights, dim3(grid), dim3(256), lds_bytes, stream, R);
+        else hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(256), lds_bytes, stream, R);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     if (flags & HRT_FLAG_GAMMA) {
@@ -516,6 +571,11 @@ int hrt_last_kernel_ms(hrt_scene *s, double *ms) {
     if (!s || !ms) return fail(HRT_ERR_INVALID, "hrt_last_kernel_ms: NULL argument");
     if (!s->timed) { *ms = 0.0; return HRT_OK; }
     HIP_TRY(hipEventSynchronize(s->ev1));
+    {
+        unsigned long long gave_up = 0;
+        HIP_TRY(hipMemcpy(&gave_up, s->stamps + 15, sizeof(gave_up), hipMemcpyDeviceToHost));
+        if (gave_up) return fail(HRT_ERR_DEVICE, "trace kernel gave up: scheduler cycle bound exceeded");
+    }
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, s->ev0, s->ev1));
     *ms = (double)f;
@@ -531,6 +591,13 @@ int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded, 
     hipLaunchKernelGGL(hrt_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_gathered,
                        tiles_per_rank_padded, w, h, world, d_frame);
     HIP_TRY(hipGetLastError());
+    return HRT_OK;
+}
+
+int hrt_debug_read_stamps(hrt_scene *s, uint64_t out[16]) {
+    if (!s || !out) return fail(HRT_ERR_INVALID, "hrt_debug_read_stamps: NULL argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, s->stamps, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return HRT_OK;
 }
 
@@ -570,13 +637,14 @@ int hrt_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         double ms = 0.0;
-        (void)hrt_last_kernel_ms(s, &ms);
+        rc = hrt_last_kernel_ms(s, &ms);
+        if (rc != HRT_OK) return rc;
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stats->samples = (uint64_t)w * h * spp;
         stats->vgprs = (uint32_t)g_rt.attr.numRegs;
-        stats->lds_bytes = s->lds_units * 16u;
-        stats->waves_launched = s->last_grid * 4u;
+        stats->lds_bytes = s->last_lds;
+        stats->waves_launched = s->last_waves;
     }
     return HRT_OK;
 }

@@ -66,9 +66,16 @@ struct DScene {
 };
 
 struct DCamera {
-    double mv_inv[16];  // inverse modelview, column-major (matrixUtilities.h:36)
-    double p_inv[16];   // inverse projection (matrixUtilities.h:42)
-    float eye[3];       // cameraSpaceToWorldSpace(0,0,0), matrixUtilities.h:53-58
+    // The two fp64 mat-vecs of matrixUtilities.h:60-68 with their structural zeros removed.  With
+    // P^-1 = [pi0 . . .; . pi5 . .; . . . -1; . . pi11 pi15] (column-major p_inv[0,5,11,14,15]) and
+    // MV^-1 = [right up -forward eye; 0 0 0 1], the reference's left-to-right sums reduce EXACTLY to
+    //   ri = (pi0*x, pi5*y, -1, pi15)      r_k = ((mx[k]*ri0 + my[k]*ri1) + c1[k]) + c2[k]      r_3 = pi15
+    // because adding (+-)0 and multiplying by -1 or 1 round nothing.
+    double pi0, pi5, pi15, inv15;  // inv15 = 1/pi15 (fast path of the division, see camera_ray)
+    double mx[3], my[3];           // MV^-1 columns 0 and 1
+    double c1[3];                  // MV^-1 column 2 times ri2 = -1           (exact)
+    double c2[3];                  // fl64(MV^-1 column 3 * pi15)             (one rounding, as the reference)
+    float eye[3];                  // cameraSpaceToWorldSpace(0,0,0), matrixUtilities.h:53-58
     float pad;
 };
 
@@ -87,4 +94,6 @@ struct DRender {
     float err_abs;             // 2e-6 * (largest |coordinate| of scene + camera): margin of the no-division filters
     float *out_tiles;          // tiles_owned * 64 * 3 floats, tile-major
     uint32_t *tile_counter;    // work queue head, zeroed before every launch
+    unsigned long long *stamps;  // 16 cycle counters, written only by -DHRT_STAMPS diagnostic builds
+    float *sp_scratch;           // streaming kernel: per-workgroup [sample][pixel][rgb] scratch of one sample chunk
 };

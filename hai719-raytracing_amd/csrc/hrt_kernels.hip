@@ -43,6 +43,22 @@ namespace hrtk {
 // because (float)1e-5 < 1e-5 < nextafterf((float)1e-5, 1).
 #define HRT_T_ACCEPT(t) ((t) > HRT_EPS)
 
+// Diagnostic build only (-DHRT_STAMPS): cycles per stage, accumulated per wave in LDS by lane 0 and
+// added to DRender::stamps at the end.  The shipped kernel executes no stamp.
+#ifdef HRT_STAMPS
+// wave-uniform accumulators in registers: cx.st[0..15] = cycles per stage, cx.st[16] = previous stamp
+#define STAMP(k)                                                      \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        cx.st[k] += t_ - cx.st[16];                                   \
+        cx.st[16] = t_;                                               \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // u8 -> float tables built on the host in double: [0,256) = c/255., [256,512) = c/127.5 - 1.
 __constant__ float c_u8_lut[512];
 
@@ -128,6 +144,7 @@ struct Ctx {
     lu4 lds;         // nodelets staged in LDS
     uint32_t lds_n;  // how many
     float err_abs;   // margin scale of the filters
+    unsigned long long *st;  // diagnostic stamps (HRT_STAMPS builds), else unused
 };
 
 // ------------------------------------------------------------------ primitives
@@ -210,7 +227,11 @@ __device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) {
     const bool finite = big < 1e30f;  // a zero direction component makes a slab distance infinite
     if (finite && g1 < g0 - mg) return false;
     if (finite && g1 > g0 + mg) return true;
+#ifdef HRT_ABL_NO_EXACT_GATE  // ablation only: timing experiment, not parity-safe
+    return true;
+#else
     return aabb_gate_exact(M, ray);
+#endif
 }
 
 // Nodelet fetch: the leading `lds_n` units of the kd array are resident in LDS.
@@ -325,6 +346,7 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
         float t;
         if (sphere_t(ld(sph, 2 * i), ld(sph, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
     }
+    STAMP(1);
     cf4 qd = (cf4)S->quads;
     const uint32_t nq = S->n_quads;
     if (nq <= 64u) {
@@ -334,11 +356,18 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
         // in index order with the reference's strict `<`, so the selected hit is the reference's.
         uint64_t cand = 0ull;
         float tsure = h.t;  // upper bound on the exact t of a hit that certainly exists
+        // rows of quad i+1 are requested before quad i is evaluated, so the scalar-load latency
+        // (s_load_dwordx4 x4) overlaps ~45 VALU instructions instead of stalling every trip
+        float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+        if (nq) { n0 = ld(qd, 0); n1 = ld(qd, 1); n2 = ld(qd, 2); n3 = ld(qd, 3); }
         for (uint32_t i = 0; i < nq; ++i) {
-            const float4 q1 = ld(qd, HRT_QUAD_ROWS * i + 1);
+            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+            if (i + 1 < nq) {
+                n0 = ld(qd, HRT_QUAD_ROWS * (i + 1)); n1 = ld(qd, HRT_QUAD_ROWS * (i + 1) + 1);
+                n2 = ld(qd, HRT_QUAD_ROWS * (i + 1) + 2); n3 = ld(qd, HRT_QUAD_ROWS * (i + 1) + 3);
+            }
             const uint32_t flags = __float_as_uint(q1.w);
             if (flags & HRT_QUAD_FLAG_MOVING) { cand |= 1ull << i; continue; }  // uniform branch; the exact path decides
-            const float4 q0 = ld(qd, HRT_QUAD_ROWS * i), q2 = ld(qd, HRT_QUAD_ROWS * i + 2), q3 = ld(qd, HRT_QUAD_ROWS * i + 3);
             const f3 n = mk(q1);
             const float dotRN = dot(ray.d, n);                    // exact: the sign tests are the reference's
             const bool front = (flags & HRT_QUAD_FLAG_GLASS) ? (dotRN != 0.f) : (dotRN < 0.f);
@@ -356,6 +385,7 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
             if (loose) cand |= 1ull << i;
             if (sure) tsure = fminf(tsure, ta * (1.f + 1e-6f));
         }
+        STAMP(2);
         gf4 gq = (gf4)S->quads;
         while (cand) {
             const uint32_t i = (uint32_t)__builtin_ctzll(cand);
@@ -663,11 +693,22 @@ __device__ __forceinline__ void mult4(M m, double x, double y, double z, double 
     r[2] = m[2] * x + m[6] * y + m[10] * z + m[14] * w;
     r[3] = m[3] * x + m[7] * y + m[11] * z + m[15] * w;
 }
+// (float)(r / pi15) without the fp64 division: q = r * (1/pi15) is within 3.4e-16 |q| of the correctly
+// rounded quotient; if the ends of that interval narrow to the same float, so does the quotient
+// (rounding is monotonic).  Otherwise (about 1e-8 of the calls) the exact division is done.
+__device__ __forceinline__ float div_narrow(double r, double d, double inv_d) {
+    const double q = r * inv_d;
+    const float lo = (float)(q * (1.0 - 8.881784197001252e-16)), hi = (float)(q * (1.0 + 8.881784197001252e-16));  // 1 -+ 2^-50
+    return (lo == hi) ? lo : (float)(r / d);
+}
 __device__ __forceinline__ Ray camera_ray(ccam C, float u, float v, float time) {
-    double ri[4], r[4];
-    mult4(C->p_inv, 2.0 * (double)u - 1.0, -(2.0 * (double)v - 1.0), 0.0, 1.0, ri);
-    mult4(C->mv_inv, ri[0], ri[1], ri[2], ri[3], r);
-    const f3 world = mk((float)(r[0] / r[3]), (float)(r[1] / r[3]), (float)(r[2] / r[3]));
+    const double ri0 = C->pi0 * (2.0 * (double)u - 1.0);
+    const double ri1 = C->pi5 * -(2.0 * (double)v - 1.0);
+    const double d = C->pi15, inv_d = C->inv15;
+    const double r0 = ((C->mx[0] * ri0 + C->my[0] * ri1) + C->c1[0]) + C->c2[0];
+    const double r1 = ((C->mx[1] * ri0 + C->my[1] * ri1) + C->c1[1]) + C->c2[1];
+    const double r2 = ((C->mx[2] * ri0 + C->my[2] * ri1) + C->c1[2]) + C->c2[2];
+    const f3 world = mk(div_narrow(r0, d, inv_d), div_narrow(r1, d, inv_d), div_narrow(r2, d, inv_d));
     Ray out;
     out.o = mk(C->eye[0], C->eye[1], C->eye[2]);
     // normalised twice, as the reference does: once in screen_space_to_world_space_ray
@@ -694,6 +735,12 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
         gu4 g_units = (gu4)cx.S->kd_units;
         for (uint32_t i = threadIdx.x; i < cx.lds_n; i += blockDim.x) s_units[i] = ld(g_units, i);
     }
+    unsigned long long stamps_local[17];
+    cx.st = stamps_local;
+#ifdef HRT_STAMPS
+    for (int k = 0; k < 16; ++k) stamps_local[k] = 0ull;
+    stamps_local[16] = __builtin_readcyclecounter();
+#endif
     __syncthreads();
     const bool has_mesh = cx.S->n_meshes != 0u;
 
@@ -736,10 +783,13 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                     rad = mk(0.f, 0.f, 0.f);
                     remaining = 6;  // MAXBOUNCES
                 }
+                STAMP(0);
                 h = prims_hit(cx, ray);
+                STAMP(3);
                 parked = has_mesh ? mesh_gates(cx, ray) : 0u;
                 stage = parked ? 1u : 2u;
             }
+            STAMP(4);
             // ---- stage B: walk the meshes for the parked lanes once enough of them have gathered
             if (has_mesh) {
                 const uint64_t waiting = __ballot(live && stage == 1u);
@@ -751,6 +801,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                     }
                 }
             }
+            STAMP(5);
             // ---- stage C: shade, scatter, end of path
             if (live && stage == 2u) {
                 bool ended;
@@ -759,11 +810,14 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                     ended = true;
                 } else {
                     const Surface sf = shade(cx.S, ray, h);
+                    STAMP(6);
                     f3 direct = mk(0.f, 0.f, 0.f);
                     if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
+                    STAMP(7);
                     rad = rad + thr * (direct + sf.emission);
                     thr = thr * sf.albedo;
                     scatter(sf, ray, rng);
+                    STAMP(8);
                     --remaining;
                     ended = (remaining == 0);
                 }
@@ -775,6 +829,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                 }
                 stage = 0u;
             }
+            STAMP(9);
         }
         float *o = R.out_tiles + ((size_t)j * 64u + lane) * 3u;
         f3 c = mk(0.f, 0.f, 0.f);
@@ -783,7 +838,12 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
             c = mk(sum.x / nspp, sum.y / nspp, sum.z / nspp);  // main.cpp:195
         }
         o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        STAMP(10);
     }
+#ifdef HRT_STAMPS
+    if ((threadIdx.x & 63u) == 0u && R.stamps)
+        for (int k = 0; k < 16; ++k) atomicAdd(R.stamps + k, stamps_local[k]);
+#endif
 }
 
 }  // namespace hrtk
@@ -826,6 +886,8 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
     cx.lds = (lu4) nullptr;
     cx.lds_n = 0;  // every nodelet from global memory here
     cx.err_abs = R.err_abs;
+    unsigned long long stamps_local[17] = {0};
+    cx.st = stamps_local;
     const Ray ray = camera_ray((ccam)R.cam, ((float)x + 0.5f) / (float)R.w, ((float)y + 0.5f) / (float)R.h, 0.f);
     const Hit h = closest_hit(cx, ray);
     f3 o = mk(0.f, 0.f, 0.f);

@@ -158,7 +158,8 @@ typedef struct hrt_camera {
 
 enum {
     HRT_FLAG_GAMMA = 1u,       /* apply pow(c,1/2.2) (main.cpp:196)             */
-    HRT_FLAG_NO_LDS_TREE = 2u  /* debug: fetch every nodelet from global memory */
+    HRT_FLAG_NO_LDS_TREE = 2u, /* debug: fetch every nodelet from global memory */
+    HRT_FLAG_WAVE_KERNEL = 4u  /* use the lane-per-pixel kernel instead of the workgroup-streaming one */
 };
 
 typedef struct hrt_stats {
@@ -214,6 +215,10 @@ int hrt_render_aov(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t
 /* Draws 0..n-1 of the per-path RNG stream (seed, pixel, sample) as the kernel
  * produces them (DESIGN.md "RNG stream").  out: host, n floats. */
 int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out);
+
+/* Cycle counters per kernel stage of the last launch; all zero unless libhrt.so was built with
+ * -DHRT_STAMPS (diagnostic build, tools/variants.sh).  out: 16 values. */
+int hrt_debug_read_stamps(hrt_scene *scene, uint64_t out[16]);
 
 /* Output stage of main.cpp:252-262: P3 ASCII with (int)(255*min(1,c)). */
 int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);

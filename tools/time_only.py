@@ -24,4 +24,12 @@ for name in scenes:
     for _ in range(5):
         _, st = dev.render(cam, w, h, spp, 1); ms.append(st.kernel_ms)
     ms = np.array(ms)
+    import ctypes as C
+    st16 = (C.c_uint64 * 16)()
+    hrt.device_lib().hrt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    hrt.device_lib().hrt_debug_read_stamps(dev._h, st16)
+    tot = sum(st16) or 1
+    if sum(st16):
+        names = ["regen", "spheres", "quad_filter", "quad_refine", "gates", "mesh_stage", "shade", "direct", "scatter", "end", "tile_io"]
+        print("   stamps %: " + "  ".join(f"{n} {100*st16[i]/tot:.1f}" for i, n in enumerate(names)), flush=True)
     print(f"{tag:28s} {name:15s} {w}x{h}@{spp}: min {ms.min():8.2f} ms  med {np.median(ms):8.2f} ms -> {w*h*spp/ms.min()/1e3:8.1f} Msamples/s  vgpr {st.vgprs} waves {st.waves_launched} lds {st.lds_bytes}  bad_px {bad*100:.3f}%", flush=True)
