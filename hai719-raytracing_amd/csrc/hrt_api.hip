@@ -3,6 +3,7 @@
 // with HRT_ERR_DEVICE when HIP cannot provide one.
 #include "hrt_kernels.hip"
 #include "hrt_stream.hip"
+#include "hrt_dual.hip"
 
 #include <chrono>
 #include <cmath>
@@ -32,6 +33,7 @@ struct Runtime {
     int cus = 0;
     int blocks_per_cu = 0;
     uint32_t lds_budget = 0;  // bytes of dynamic LDS per workgroup for nodelets
+    bool use_dual = true;     // two pixel streams per lane (hrt_dual.hip) for scenes with meshes; HRT_KERNEL=single turns it off
     bool use_stream = false;  // workgroup-streaming kernel (hrt_stream.hip), opt-in with HRT_KERNEL=stream
     hipFuncAttributes attr{};
 } g_rt;
@@ -85,6 +87,7 @@ struct hrt_scene {
     DCamera h_cam{};
     bool cam_valid = false;
     uint32_t lds_units = 0;
+    uint32_t max_leaf = 0;       // most triangles in one KD leaf (the resumable walk keeps a 16-bit leaf cursor)
     std::vector<void *> allocations;
     uint32_t *tile_counter = nullptr;
     unsigned long long *stamps = nullptr;  // diagnostic cycle counters (HRT_STAMPS builds)
@@ -122,7 +125,7 @@ int hrt_init(int device_ordinal) {
     HIP_TRY(hipFuncGetAttributes(&g_rt.attr, (const void *)hrt_trace_kernel));
     // LDS for nodelets per 256-thread workgroup.  Default 32 KiB (4 workgroups/CU keep 128 of the
     // CU's 160 KiB); HRT_LDS_KB overrides for tuning.
-    uint32_t kb = 32;
+    uint32_t kb = 36u * (HRT_WG / 256u);  // 4 x 36 KiB (HRT_WG 256) or 1 x 144 KiB (HRT_WG 1024) of the CU's 160 KiB
     if (const char *e = std::getenv("HRT_LDS_KB")) kb = (uint32_t)std::max(0, atoi(e));
     if (kb > 160) kb = 160;
     g_rt.lds_budget = kb * 1024u;
@@ -131,6 +134,10 @@ int hrt_init(int device_ordinal) {
                                     (int)g_rt.lds_budget));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g_rt.lds_budget));
+    }
+    if (HRT_WG > 256) {  // one big workgroup per CU: backed-up streams + nodelets go past the 64 KiB default
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace2_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     {   // u8 -> float tables in double, as the reference evaluates c/255. and c/127.5 - 1. (Material.cpp:87,124)
         float lut[512];
@@ -142,6 +149,7 @@ int hrt_init(int device_ordinal) {
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const char *k = std::getenv("HRT_KERNEL");
+        g_rt.use_dual = !(k && std::string(k) == "single");
         g_rt.use_stream = (k && std::string(k) == "stream");  // opt-in until it beats the lane-per-pixel kernel
     }
     g_rt.ready = true;
@@ -314,6 +322,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 const hrt_kdunit *u = M.kd_units + idx;
                 if (ref & HRT_KD_LEAF) {
                     if ((uint64_t)u[0].w[3] + u[1].w[3] > M.n_leaf_tris) { ok = false; break; }
+                    s->max_leaf = std::max(s->max_leaf, u[1].w[3]);
                     units[unit_base + idx] = make_uint4(u[0].w[0], u[0].w[1], u[0].w[2], u[0].w[3]);
                     units[unit_base + idx + 1] = make_uint4(u[1].w[0], u[1].w[1], u[1].w[2], u[1].w[3]);
                     uint32_t r[6];
@@ -516,14 +525,17 @@ int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h
     R.out_tiles = d_tiles;
     hipStream_t stream = (hipStream_t)stream_;
     if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
-    const bool stream_kernel = g_rt.use_stream && !(flags & HRT_FLAG_WAVE_KERNEL);
+    const bool stream_kernel = (g_rt.use_stream || (flags & HRT_FLAG_STREAM_KERNEL)) && !(flags & HRT_FLAG_WAVE_KERNEL);
+    const bool dual_kernel = !stream_kernel && g_rt.use_dual && s->d.n_meshes > 0u && s->max_leaf < 0xFFFFu && !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
-        const uint32_t fixed = (uint32_t)(SP_FIELDS * HRT_SP_POOL * 4 + 8 * HRT_SP_POOL * 2 + sizeof(SpCtl) + 256 * 4);
-        const uint32_t room = (160u * 1024u - fixed) / 16u;
+        const uint32_t fixed = (uint32_t)(SP_FIELDS * HRT_SP_POOL * 4 + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + 256 * 4);
+        uint32_t per_cu = 1024u / HRT_SP_WG;  // workgroups resident per CU (4 waves per SIMD in all) ...
+        while (per_cu > 1u && 160u * 1024u / per_cu < fixed + 16u * 1024u) --per_cu;  // ... as far as the LDS pools allow
+        const uint32_t room = (160u * 1024u / per_cu - fixed) / 16u;
         if (!(flags & HRT_FLAG_NO_LDS_TREE)) R.lds_units = std::min<uint32_t>(s->d.n_kd_units, room);
         lds_bytes = fixed + R.lds_units * 16u;
-        grid = std::min<uint32_t>((uint32_t)g_rt.cus, R.tiles_owned);  // one workgroup per CU
+        grid = std::min<uint32_t>((uint32_t)g_rt.cus * per_cu, R.tiles_owned);
         const size_t need_floats = (size_t)grid * 64u * HRT_SP_SCHUNK * 3u;
         if (s->sp_scratch_cap < need_floats) {
             if (s->sp_scratch) (void)hipFree(s->sp_scratch);
@@ -533,19 +545,29 @@ int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h
         }
         R.sp_scratch = s->sp_scratch;
     } else {
-        lds_bytes = R.lds_units * 16u;
-        int per_cu = 0;
         const void *kfn = s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds_bytes));
+        lds_bytes = R.lds_units * 16u;
+        if (dual_kernel) {
+            // 4 workgroups per CU: 160 KiB = 4 x (27 KiB of backed-up streams + 12 KiB of nodelets)
+            const uint32_t wgs = 1024u / HRT_WG, backup = HRT_DS_FIELDS * HRT_WG * 4u;
+            const uint32_t room = (156u * 1024u / wgs - backup) / 16u;
+            if (R.lds_units > room) R.lds_units = room;
+            lds_bytes = R.lds_units * 16u + backup;
+            kfn = s->d.n_lights ? (const void *)hrt_trace2_kernel_lights : (const void *)hrt_trace2_kernel;
+        }
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, HRT_WG, lds_bytes));
         if (per_cu < 1) per_cu = 1;
         grid = (uint32_t)(per_cu * g_rt.cus);
-        const uint32_t need = (R.tiles_owned + 3u) / 4u;  // 4 waves per workgroup, one tile per wave at a time
+        // 4 waves per workgroup, one tile (two in the dual-stream kernel) per wave at a time
+        const uint32_t per_wg = (HRT_WG / 64u) * (dual_kernel ? 2u : 1u);
+        const uint32_t need = (R.tiles_owned + per_wg - 1u) / per_wg;
         if (grid > need) grid = need;
         R.sp_scratch = nullptr;
     }
     s->last_grid = grid;
     s->last_lds = lds_bytes;
-    s->last_waves = stream_kernel ? grid * (HRT_SP_WG / 64) : grid * 4u;
+    s->last_waves = stream_kernel ? grid * (HRT_SP_WG / 64) : grid * (HRT_WG / 64u);
     HIP_TRY(hipMemsetAsync(s->tile_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(s->stamps, 0, 16 * sizeof(unsigned long long), stream));  // [15] = give-up code of the streaming kernel
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -553,8 +575,11 @@ int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h
         if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
         else hipLaunchKernelGGL(hrt_wgstream_kernel, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
     } else {
-        if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace_kernel_lights, dim3(grid), dim3(256), lds_bytes, stream, R);
-        else hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(256), lds_bytes, stream, R);
+        if (dual_kernel) {
+            if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace2_kernel_lights, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
+            else hipLaunchKernelGGL(hrt_trace2_kernel, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
+        } else if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace_kernel_lights, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
+        else hipLaunchKernelGGL(hrt_trace_kernel, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));

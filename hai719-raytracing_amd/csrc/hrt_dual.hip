@@ -1,0 +1,380 @@
+// hrt_trace2_kernel -- the lane-per-pixel megakernel with TWO pixel streams per lane (mesh scenes).
+// Included by hrt_api.hip after hrt_kernels.hip; every arithmetic function is the one the single-stream
+// kernel uses, so results are bit-identical to it.
+//
+// WHY.  In hrt_trace_kernel the KD walk (stage B) only runs for the lanes whose ray entered a mesh box:
+// about 30 % of the rays on Cornell+mesh, so the most expensive stage runs at 15-25 % lane occupancy,
+// and the lanes parked for it idle through the other lanes' stage A/C iterations.  Here a wave owns two
+// 8x8 tiles at a time and each lane two pixels, one per tile: the state of one pixel stream lives in
+// registers ("active"), the other in a lane-private LDS slot ("backup", 27 dwords, SoA, conflict free,
+// no atomics and no barriers: nobody else ever touches it).  A lane whose active stream is parked for
+// stage B swaps to its other stream and keeps tracing; stage B fires when most lanes have SOME stream
+// parked (HRT_DS_ANY), or too many lanes have nothing else left to do (HRT_DS_BLOCKED), and then walks
+// up to two rays per lane.  Stage B therefore runs with most lanes occupied, and A/C lose lanes only
+// when both of a lane's streams wait.
+//
+// Each stream is one pixel with its samples in order, exactly as in the single-stream kernel, so the
+// schedule cannot change random numbers, arithmetic, or the order of the pixel sum (main.cpp:193).
+#include "hrt_device.h"
+
+#ifndef HRT_DS_ANY
+#define HRT_DS_ANY 48      // lanes with a parked stream that trigger stage B
+#endif
+#ifndef HRT_DS_BLOCKED
+#define HRT_DS_BLOCKED 16  // lanes with nothing runnable that trigger stage B
+#endif
+#ifndef HRT_DS_SECOND
+#define HRT_DS_SECOND 8    // lanes with a second parked stream that make a second pass worth while
+#endif
+#ifndef HRT_DS_TRIPS
+#define HRT_DS_TRIPS 8     // KD-walk trips per stage B visit; an unfinished walk resumes at the next visit
+#endif
+#define HRT_DS_FIELDS 34   // dwords of one backed-up stream
+#define HRT_DS_NONE 0xFFFFFFFFu
+
+namespace hrtk {
+
+// A KD walk that can stop after any trip and resume later (same trips, same order, same arithmetic
+// as mesh_traverse: only where the loop is cut changes).
+struct Walk {
+    uint32_t ref;      // next nodelet, HRT_KD_NIL = no walk in progress
+    float t_entry;     // entry distance of the current cell
+    uint32_t kk;       // trips so far << 16 | triangle cursor of the current leaf (0xFFFF: leaf not entered yet)
+    float best_t;      // closest triangle of THIS mesh so far (KDTree.cpp:44), merged into the hit when the walk ends
+    uint32_t best_tri;
+    float bu, bv;
+};
+
+struct PathState {
+    Ray ray;
+    f3 thr, rad, sum;
+    Rng rng;
+    Hit h;
+    Walk w;
+    uint32_t parked;   // meshes still to be walked for the current ray
+    uint32_t stage;    // 0: needs stage A   1: parked for stage B   2: ready for stage C
+    uint32_t s;        // next sample of the pixel
+    int remaining;     // bounces left on the current path; 0 = needs a new path
+    bool live;         // the pixel still has samples to trace
+};
+
+__device__ __forceinline__ uint32_t ds_flags(const PathState &p) { return p.stage | ((uint32_t)p.remaining << 2) | (p.live ? 0x100u : 0u); }
+__device__ __forceinline__ bool fl_live(uint32_t fl) { return (fl & 0x100u) != 0u; }
+__device__ __forceinline__ bool fl_waiting(uint32_t fl) { return (fl & 0x103u) == 0x101u; }
+__device__ __forceinline__ bool fl_runnable(uint32_t fl) { return fl_live(fl) && (fl & 3u) != 1u; }
+
+// the float and integer fields of a stream in their LDS order
+#define HRT_DS_FLOATS(F)                                                                              \
+    F(0, p.ray.o.x) F(1, p.ray.o.y) F(2, p.ray.o.z) F(3, p.ray.d.x) F(4, p.ray.d.y) F(5, p.ray.d.z)   \
+    F(6, p.ray.time) F(7, p.thr.x) F(8, p.thr.y) F(9, p.thr.z) F(10, p.rad.x) F(11, p.rad.y)          \
+    F(12, p.rad.z) F(13, p.sum.x) F(14, p.sum.y) F(15, p.sum.z) F(16, p.h.t) F(17, p.h.a0) F(18, p.h.a1) \
+    F(27, p.w.t_entry) F(28, p.w.best_t) F(29, p.w.bu) F(30, p.w.bv)
+#define HRT_DS_UINTS(U) U(19, p.rng.k0) U(20, p.rng.k1) U(21, p.rng.i) U(22, p.h.tri) U(23, p.parked) U(24, p.s) \
+    U(31, p.w.ref) U(32, p.w.kk) U(33, p.w.best_tri)
+// 25: hit kind | index   26: flags
+
+__device__ __forceinline__ void ds_store(uint32_t *sb, const PathState &p) {
+    const uint32_t i = threadIdx.x;
+#define F(k, v) sb[(k) * (uint32_t)HRT_WG + i] = __float_as_uint(v);
+#define U(k, v) sb[(k) * (uint32_t)HRT_WG + i] = (v);
+    HRT_DS_FLOATS(F) HRT_DS_UINTS(U)
+#undef F
+#undef U
+    sb[25u * (uint32_t)HRT_WG + i] = (p.h.kind << 28) | p.h.index;
+    sb[26u * (uint32_t)HRT_WG + i] = ds_flags(p);
+}
+
+__device__ __forceinline__ void ds_load(const uint32_t *sb, PathState &p) {
+    const uint32_t i = threadIdx.x;
+#define F(k, v) v = __uint_as_float(sb[(k) * (uint32_t)HRT_WG + i]);
+#define U(k, v) v = sb[(k) * (uint32_t)HRT_WG + i];
+    HRT_DS_FLOATS(F) HRT_DS_UINTS(U)
+#undef F
+#undef U
+    const uint32_t hid = sb[25u * (uint32_t)HRT_WG + i], fl = sb[26u * (uint32_t)HRT_WG + i];
+    p.h.kind = hid >> 28; p.h.index = hid & 0x0FFFFFFFu;
+    p.stage = fl & 3u; p.remaining = (int)((fl >> 2) & 63u); p.live = fl_live(fl);
+}
+
+// registers <-> this lane's LDS slot; returns the flags of the stream that went to LDS
+__device__ __forceinline__ uint32_t ds_swap(uint32_t *sb, PathState &p) {
+    PathState q;
+    ds_load(sb, q);
+    const uint32_t fl = ds_flags(p);
+    ds_store(sb, p);
+    p = q;
+    return fl;
+}
+
+__device__ __forceinline__ void ds_fresh(PathState &p, bool live) {
+    p.ray.o = mk(0.f, 0.f, 0.f); p.ray.d = mk(0.f, 0.f, 1.f); p.ray.time = 0.f;
+    p.thr = mk(1.f, 1.f, 1.f); p.rad = mk(0.f, 0.f, 0.f); p.sum = mk(0.f, 0.f, 0.f);
+    p.rng.k0 = p.rng.k1 = p.rng.i = 0;
+    p.h.kind = 0; p.h.index = 0; p.h.t = HRT_FLT_MAX; p.h.tri = 0; p.h.a0 = 0.f; p.h.a1 = 0.f;
+    p.w.ref = HRT_KD_NIL; p.w.t_entry = 0.f; p.w.kk = 0xFFFFu; p.w.best_t = HRT_FLT_MAX; p.w.best_tri = 0; p.w.bu = 0.f; p.w.bv = 0.f;
+    p.parked = 0; p.stage = 0; p.s = 0; p.remaining = 0; p.live = live;
+}
+
+// Up to `trips` trips of the walk of mesh M (mesh_traverse's loop body, KDTree.cpp:31-85 semantics);
+// true when the walk is complete: w.best_* then hold the mesh's closest triangle with t >= 0, if any.
+__device__ __forceinline__ bool mesh_walk(const Ctx &cx, cmesh M, const Ray &ray, f3 inv, Walk &w, int trips) {
+    if (w.ref == HRT_KD_NIL) {  // start: clip the ray to the root cell
+        float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
+        float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
+        t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
+        t0 = (M->kd_lo[1] - ray.o.y) * inv.y; t1 = (M->kd_hi[1] - ray.o.y) * inv.y;
+        t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
+        t0 = (M->kd_lo[2] - ray.o.z) * inv.z; t1 = (M->kd_hi[2] - ray.o.z) * inv.z;
+        t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
+        w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
+        if (!(t_entry <= t_scene_exit)) return true;
+        w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
+    }
+    gu4 g_units = (gu4)cx.S->kd_units;
+    gf4 tris = (gf4)cx.S->tris;
+    const uint32_t tri_base = M->tri_base;
+    uint32_t ref = w.ref, k = w.kk & 0xFFFFu, count = w.kk >> 16;
+    float t_entry = w.t_entry;
+    f3 p = ray.o + t_entry * ray.d;
+    for (int trip = 0; trip < trips && ref != HRT_KD_NIL; ++trip) {
+#pragma unroll
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            if (!(ref & HRT_KD_LEAF)) {
+                const uint4 nd = kd_fetch(g_units, cx, ref);
+                const float split = __uint_as_float(nd.x);
+                const float pc = comp(p, nd.y), dc = comp(ray.d, nd.y);
+                const bool left = (pc < split) || (pc == split && dc < 0.f);
+                ref = left ? nd.z : nd.w;
+            }
+        }
+        if (ref & HRT_KD_LEAF) {
+            const uint32_t lu = ref & ~HRT_KD_LEAF;
+            const uint4 l0 = kd_fetch(g_units, cx, lu);
+            const uint4 l1 = kd_fetch(g_units, cx, lu + 1);
+            const uint32_t first = tri_base + l0.w, cnt = l1.w;
+            if (k == 0xFFFFu) k = 0;
+            if (k < cnt) {
+                gf4 tr = tris + HRT_TRI_ROWS * (first + k);
+                const float4 r3 = ld(tr, 3);
+                const f3 n = mk(r3);
+                const float dotRN = dot(ray.d, n);
+                if (dotRN < 0.f) {                                     // Triangle.h:80-91: else parallel / back-facing (NaN: no hit)
+                    const float t = (r3.w - dot(ray.o, n)) / dotRN;    // :95
+                    if (!(t < 0.f) && t < w.best_t) {                  // :96, then the leaf's strict `<` (KDTree.cpp:44)
+                        const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
+                        const f3 v2 = (ray.o + t * ray.d) - mk(r0);
+                        const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
+                        const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;  // Triangle.h:72-74
+                        const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
+                        const float u0 = 1 - u1 - u2;
+                        if (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1) {
+                            w.best_t = t; w.best_tri = first + k; w.bu = u1; w.bv = u2;
+                        }
+                    }
+                }
+                ++k;
+            }
+            if (k >= cnt) {  // leave the cell through its exit face
+                const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
+                const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
+                const float ez = ((ray.d.z > 0.f ? __uint_as_float(l1.z) : __uint_as_float(l0.z)) - ray.o.z) * inv.z;
+                float t_exit = HRT_FLT_MAX;
+                uint32_t face = 6;
+                if (ray.d.x != 0.f && ex < t_exit) { t_exit = ex; face = ray.d.x > 0.f ? 1u : 0u; }
+                if (ray.d.y != 0.f && ey < t_exit) { t_exit = ey; face = ray.d.y > 0.f ? 3u : 2u; }
+                if (ray.d.z != 0.f && ez < t_exit) { t_exit = ez; face = ray.d.z > 0.f ? 5u : 4u; }
+                if (w.best_t <= t_exit || face == 6) {
+                    ref = HRT_KD_NIL;  // the closest hit lies inside the cells already visited
+                } else {
+                    t_entry = fmaxf(t_entry, t_exit);
+                    p = ray.o + t_entry * ray.d;
+                    const uint4 rp = kd_fetch(g_units, cx, lu + 2 + (face >> 2));
+                    const uint32_t sel = face & 3u;
+                    ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
+                    k = 0xFFFFu;
+                }
+            }
+        }
+        if (++count >= 8192u) ref = HRT_KD_NIL;  // mesh_traverse's bound on the whole walk
+    }
+    w.ref = ref; w.t_entry = t_entry; w.kk = (count << 16) | k;
+    return ref == HRT_KD_NIL;
+}
+
+// One stage B visit for a parked stream: HRT_DS_TRIPS trips on each mesh in turn (Scene.h:222-228 order).
+__device__ __forceinline__ void walk_visit(const Ctx &cx, PathState &p) {
+    const f3 inv = ray_inv(p.ray);
+    const uint32_t nm = min(cx.S->n_meshes, 32u);
+    for (uint32_t i = 0; i < nm; ++i) {  // wave-uniform loop: scalar mesh records
+        if ((p.parked & (0u - p.parked)) == (1u << i)) {  // mesh i is this lane's next one
+            if (mesh_walk(cx, (cmesh)cx.S->meshes + i, p.ray, inv, p.w, HRT_DS_TRIPS)) {
+                const float t = p.w.best_t;
+                if (t < HRT_FLT_MAX && t < p.h.t && HRT_T_ACCEPT(t)) {
+                    p.h.kind = 3; p.h.index = i; p.h.t = t; p.h.tri = p.w.best_tri; p.h.a0 = p.w.bu; p.h.a1 = p.w.bv;
+                }
+                p.parked &= ~(1u << i);
+            }
+        }
+    }
+    if (p.parked == 0u) p.stage = 2u;
+}
+
+template <bool LIGHTS>
+__device__ __forceinline__ void trace_body_dual(const DRender &R) {
+    extern __shared__ uint4 s_units[];
+    Ctx cx;
+    cx.S = (cscene)R.scene;
+    cx.lds = (lu4)s_units;
+    cx.lds_n = R.lds_units;
+    cx.err_abs = R.err_abs;
+    ccam cam = (ccam)R.cam;
+    uint32_t *sb = reinterpret_cast<uint32_t *>(s_units + R.lds_units);  // HRT_DS_FIELDS x HRT_WG dwords
+    {
+        gu4 g_units = (gu4)cx.S->kd_units;
+        for (uint32_t i = threadIdx.x; i < cx.lds_n; i += blockDim.x) s_units[i] = ld(g_units, i);
+    }
+    unsigned long long stamps_local[17];
+    cx.st = stamps_local;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    // the two tile slots of the wave (wave-uniform), and this lane's pixel in each
+    uint32_t tj[2], pxy[2];
+    uint32_t cur = 0;     // which stream is in registers
+    uint32_t bak_fl = 0;  // flags of the stream in LDS (mirror, so votes never read LDS)
+    PathState p;
+
+    auto pull = [&]() -> uint32_t {
+        uint32_t j = 0;
+        if (lane == 0) j = atomicAdd(R.tile_counter, 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        return j < R.tiles_owned ? j : HRT_DS_NONE;  // the queue is finite: every wave runs dry
+    };
+    auto locate = [&](uint32_t j, uint32_t &xy) -> bool {  // pixel of this lane in tile slot j; false = outside the image
+        if (j == HRT_DS_NONE) { xy = 0; return false; }
+        const uint32_t tile = R.rank + j * R.world;
+        const uint32_t px = (tile % R.tiles_x) * 8u + (lane & 7u), py = (tile / R.tiles_x) * 8u + (lane >> 3);
+        xy = px | (py << 16);
+        return px < R.w && py < R.h && R.spp > 0u;
+    };
+
+    tj[0] = pull();
+    tj[1] = pull();
+    {
+        const bool in1 = locate(tj[1], pxy[1]);
+        ds_fresh(p, in1);
+        ds_store(sb, p);
+        bak_fl = ds_flags(p);
+        const bool in0 = locate(tj[0], pxy[0]);
+        ds_fresh(p, in0);
+    }
+
+    for (;;) {
+        // ---- tile turnover: a slot whose 64 pixels are finished is written out and refilled
+#pragma unroll
+        for (uint32_t X = 0; X < 2u; ++X) {
+            if (tj[X] == HRT_DS_NONE) continue;
+            const bool mine = cur == X;  // the stream of slot X is in this lane's registers
+            if (__ballot(mine ? p.live : fl_live(bak_fl)) != 0ull) continue;
+            f3 sum = p.sum;
+            if (!mine) {
+                const uint32_t i = threadIdx.x;
+                sum = mk(__uint_as_float(sb[13u * (uint32_t)HRT_WG + i]), __uint_as_float(sb[14u * (uint32_t)HRT_WG + i]), __uint_as_float(sb[15u * (uint32_t)HRT_WG + i]));
+            }
+            const uint32_t px = pxy[X] & 0xFFFFu, py = pxy[X] >> 16;
+            f3 c = mk(0.f, 0.f, 0.f);
+            if (px < R.w && py < R.h) {
+                const float nspp = (float)R.spp;
+                c = mk(sum.x / nspp, sum.y / nspp, sum.z / nspp);  // main.cpp:195
+            }
+            float *o = R.out_tiles + ((size_t)tj[X] * 64u + lane) * 3u;
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+            tj[X] = pull();
+            const bool in = locate(tj[X], pxy[X]);
+            if (mine) {
+                ds_fresh(p, in);
+            } else {
+                PathState q;
+                ds_fresh(q, in);
+                ds_store(sb, q);
+                bak_fl = ds_flags(q);
+            }
+        }
+        if (tj[0] == HRT_DS_NONE && tj[1] == HRT_DS_NONE) break;
+
+        // ---- the active stream cannot run and the other one can: swap
+        if (!fl_runnable(ds_flags(p)) && fl_runnable(bak_fl)) { bak_fl = ds_swap(sb, p); cur ^= 1u; }
+
+        // ---- stage A: (re)generate, spheres + squares, mesh gates
+        if (p.live && p.stage == 0u) {
+            if (p.remaining == 0) {  // next camera sample of this pixel (main.cpp:188-192)
+                const uint32_t xy = cur ? pxy[1] : pxy[0];
+                const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
+                p.rng.start(R.seed_lo, R.seed_hi, py * R.w + px, p.s);
+                const float u = ((float)px + p.rng.next()) / (float)R.w;
+                const float v = ((float)py + p.rng.next()) / (float)R.h;
+                const float tm = p.rng.next();
+                p.ray = camera_ray(cam, u, v, tm);
+                p.thr = mk(1.f, 1.f, 1.f);
+                p.rad = mk(0.f, 0.f, 0.f);
+                p.remaining = 6;  // MAXBOUNCES
+            }
+            p.h = prims_hit(cx, p.ray);
+            p.parked = mesh_gates(cx, p.ray);
+            p.w.ref = HRT_KD_NIL;
+            p.stage = p.parked ? 1u : 2u;
+        }
+
+        // ---- stage B: walk the meshes once enough lanes hold a parked stream
+        {
+            const bool aw = p.live && p.stage == 1u, bw = fl_waiting(bak_fl);
+            const uint64_t any = __ballot(aw || bw);
+            // a lane is blocked when its active stream waits and the other one cannot run either
+            const uint64_t blocked = __ballot(aw && !fl_runnable(bak_fl));
+            const uint64_t runnable = __ballot((p.live && p.stage != 1u) || fl_runnable(bak_fl));
+            if (any != 0ull && (__popcll(any) >= HRT_DS_ANY || __popcll(blocked) >= HRT_DS_BLOCKED || runnable == 0ull)) {
+#pragma nounroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const bool a2 = p.live && p.stage == 1u, b2 = fl_waiting(bak_fl);
+                    const uint64_t want = __ballot(a2 || b2);
+                    if (want == 0ull || (pass == 1 && __popcll(want) < HRT_DS_SECOND)) break;
+                    if (!a2 && b2) { bak_fl = ds_swap(sb, p); cur ^= 1u; }  // bring the parked stream in
+                    if (p.live && p.stage == 1u) walk_visit(cx, p);
+                }
+            } else if (aw && fl_runnable(bak_fl)) {  // not yet: trace the other stream meanwhile
+                bak_fl = ds_swap(sb, p);
+                cur ^= 1u;
+            }
+        }
+
+        // ---- stage C: shade, scatter, end of path
+        if (p.live && p.stage == 2u) {
+            bool ended;
+            if (p.h.kind == 0u) {
+                p.rad = p.rad + p.thr * sky(cx.S, p.ray.d, p.remaining);
+                ended = true;
+            } else {
+                const Surface sf = shade(cx.S, p.ray, p.h);
+                f3 direct = mk(0.f, 0.f, 0.f);
+                if (LIGHTS) direct = direct_light(cx, sf, p.ray, p.rng);
+                p.rad = p.rad + p.thr * (direct + sf.emission);
+                p.thr = p.thr * sf.albedo;
+                scatter(sf, p.ray, p.rng);
+                --p.remaining;
+                ended = (p.remaining == 0);
+            }
+            if (ended) {
+                p.sum = p.sum + mk(p.rad.x / 6.f, p.rad.y / 6.f, p.rad.z / 6.f);  // Scene.h:348
+                p.remaining = 0;
+                ++p.s;
+                p.live = p.s < R.spp;
+            }
+            p.stage = 0u;
+        }
+    }
+}
+
+}  // namespace hrtk
+
+extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES) hrt_trace2_kernel(const DRender R) { hrtk::trace_body_dual<false>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES) hrt_trace2_kernel_lights(const DRender R) { hrtk::trace_body_dual<true>(R); }

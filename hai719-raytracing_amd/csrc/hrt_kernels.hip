@@ -31,6 +31,9 @@
 #ifndef HRT_MESH_BATCH
 #define HRT_MESH_BATCH 16  // parked lanes that trigger a mesh stage (A/B on MI355X: 1 -> 45.4 ms, 16 -> 43.3, 32 -> 53.4)
 #endif
+#ifndef HRT_WG
+#define HRT_WG 256        // threads per workgroup of the trace kernels; the workgroup shares one LDS copy of the nodelets
+#endif
 #ifndef HRT_MIN_WAVES
 #define HRT_MIN_WAVES 4    // waves per SIMD the register allocator must leave room for
 #endif
@@ -269,7 +272,10 @@ __device__ __forceinline__ bool mesh_traverse(const Ctx &cx, cmesh M, const Ray 
     uint32_t ref = M->root;
     uint32_t k = 0, cnt = ~0u, first = 0;  // triangle cursor of the current leaf; cnt == ~0: leaf not entered yet
     f3 p = ray.o + t_entry * ray.d;
-    for (int guard = 0; guard < 8192 && ref != HRT_KD_NIL; ++guard) {  // bounded: every wave leaves
+#ifndef HRT_ABL_GUARD
+#define HRT_ABL_GUARD 8192  // smaller values: ablation only (cuts long walks short, not parity-safe)
+#endif
+    for (int guard = 0; guard < HRT_ABL_GUARD && ref != HRT_KD_NIL; ++guard) {  // bounded: every wave leaves
 #pragma unroll
         for (int lvl = 0; lvl < 2; ++lvl) {
             if (!(ref & HRT_KD_LEAF)) {
@@ -285,6 +291,9 @@ __device__ __forceinline__ bool mesh_traverse(const Ctx &cx, cmesh M, const Ray 
             const uint4 l0 = kd_fetch(g_units, cx, lu);
             const uint4 l1 = kd_fetch(g_units, cx, lu + 1);
             if (cnt == ~0u) { first = tri_base + l0.w; cnt = l1.w; k = 0; }
+#ifdef HRT_ABL_NO_TRI  // ablation only
+            k = cnt;
+#endif
             if (k < cnt) {
                 gf4 tr = tris + HRT_TRI_ROWS * (first + k);
                 const float4 r3 = ld(tr, 3);
@@ -406,6 +415,9 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
 __device__ __forceinline__ uint32_t mesh_gates(const Ctx &cx, const Ray &ray) {
     const uint32_t nm = min(cx.S->n_meshes, 32u);
     if (nm == 0) return 0u;
+#ifdef HRT_ABL_NO_GATES  // ablation only (timing experiments, not parity-safe)
+    return 0u;
+#endif
     const f3 inv = ray_inv(ray);
     uint32_t m = 0;
     for (uint32_t i = 0; i < nm; ++i)
@@ -421,7 +433,11 @@ __device__ __forceinline__ void meshes_hit(const Ctx &cx, const Ray &ray, uint32
         if (mask & (1u << i)) {
             float t, u, v;
             uint32_t tri;
+#ifdef HRT_ABL_NO_WALK  // ablation only
+            if (false) {
+#else
             if (mesh_traverse(cx, (cmesh)cx.S->meshes + i, ray, inv, t, tri, u, v) && t < h.t && HRT_T_ACCEPT(t)) {
+#endif
                 h.kind = 3; h.index = i; h.t = t; h.tri = tri; h.a0 = u; h.a1 = v;
             }
         }
@@ -787,6 +803,10 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                 h = prims_hit(cx, ray);
                 STAMP(3);
                 parked = has_mesh ? mesh_gates(cx, ray) : 0u;
+#ifdef HRT_ABL_GATES_IGNORED  // ablation only: pay for the gates, never park
+                asm volatile("" : "+v"(parked));
+                parked &= 0x80000000u;
+#endif
                 stage = parked ? 1u : 2u;
             }
             STAMP(4);
@@ -850,8 +870,8 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
 
 using namespace hrtk;
 
-extern "C" __global__ void __launch_bounds__(256, HRT_MIN_WAVES) hrt_trace_kernel(const DRender R) { trace_body<false>(R); }
-extern "C" __global__ void __launch_bounds__(256, HRT_MIN_WAVES) hrt_trace_kernel_lights(const DRender R) { trace_body<true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES) hrt_trace_kernel(const DRender R) { trace_body<false>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES) hrt_trace_kernel_lights(const DRender R) { trace_body<true>(R); }
 
 // gamma_correct (Functions.cpp:56-60): pow(c, 1/2.2) in double, over this rank's tile buffer.  Kept out of
 // the megakernel: fp64 pow is register-hungry and runs once per pixel.

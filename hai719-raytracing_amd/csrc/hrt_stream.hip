@@ -1,25 +1,29 @@
-// hrt_stream_kernel -- the workgroup-streaming form of the trace megakernel (included by hrt_api.hip
+// hrt_wgstream_kernel -- the workgroup-streaming form of the trace megakernel (included by hrt_api.hip
 // after hrt_kernels.hip, whose exact-arithmetic device functions it reuses unchanged).
 //
 // WHY.  In hrt_trace_kernel a lane owns a pixel and walks all stages of every bounce itself; the PMC
 // profile (profiles/r01_pmc.json) shows 40 % VALU lane utilisation on Cornell+mesh because on any given
-// bounce the 64 lanes of a wave want different things (new camera ray / mesh walk / sky / glass /
-// diffuse ...).  Here the divergent rays are COMPACTED: a 1024-thread workgroup keeps a pool of
-// HRT_SP_POOL paths in LDS (SoA, 24 dwords per path) and four stage queues of 16-bit slot ids.  One
-// cycle =
-//     GEN   free slot      -> camera ray (main.cpp:188-192)                  -> PRIMS queue
-//     PRIMS ray            -> spheres + squares + mesh box gates             -> MESH or SHADE queue
-//     MESH  ray + best hit -> rope KD walk of the gated meshes               -> SHADE queue
-//     SHADE hit            -> sky | shade + direct light + scatter, path end -> PRIMS queue | free list
-// Queues are double-buffered: a cycle consumes the "in" buffers, frozen at its start, and appends to
-// the "out" buffers, so all four stages run in the SAME cycle with a single barrier pair.  The work
-// of a cycle is cut into 64-entry chunks, each homogeneous in stage; the 16 waves pull chunks from one
-// LDS cursor (dynamic balance inside the workgroup).  Appends are wave-aggregated: one __ballot, one
-// LDS atomicAdd by the leader lane, positions by popcount of the lower lanes.
+// bounce the 64 lanes of a wave want different things (new camera ray / mesh walk / shade).  Here the
+// divergent rays are COMPACTED: a workgroup keeps a pool of HRT_SP_POOL paths in LDS (SoA, 24 dwords
+// per path) and stage queues of 16-bit slot ids.  One cycle runs three kinds of 64-entry chunks:
+//     G  free slot          -> camera ray (main.cpp:188-192), spheres + squares, mesh box gates
+//     T  ray + best hit     -> rope KD walk of the gated meshes
+//     S  closest hit        -> sky | shade + direct light + scatter (path end -> free list),
+//                              then spheres + squares + gates for the scattered ray
+// G and S hand the path to T when its ray enters a mesh box, else to S.  Queues are double-buffered:
+// a cycle consumes the "in" buffers, frozen at its start, and appends to the "out" buffers, so all
+// stages run in the SAME cycle between one pair of barriers; the waves pull chunks from one LDS cursor
+// (dynamic balance inside the workgroup).  Appends are wave-aggregated: one __ballot, one LDS atomicAdd
+// by the leader lane, positions by popcount of the lower lanes (__shfl of the base).
+//
+// Every control value is written by thread 0 between two barriers and read back through
+// readfirstlane, so all loops around the barriers are provably wave-uniform for the compiler.  (With
+// per-thread copies of the same values hipcc if-converted the loop exits into exec masks and waves
+// left the barrier sequence at different points: wrong pixels, hangs.)
 //
 // DETERMINISM.  A path is keyed (pixel, sample) as before, so the schedule cannot change its random
-// numbers or its arithmetic.  Finished samples are written to a per-workgroup scratch indexed by
-// sample-major path number and folded into the pixel sum in sample order after the tile's chunk has
+// numbers or its arithmetic.  Finished samples go to a per-workgroup scratch indexed by sample-major
+// path number and are folded into the pixel sum in sample order after the tile's sample chunk has
 // drained: the fold is the reference's `image += color` order (main.cpp:193), bit for bit, whatever
 // order paths finished in.
 #include "hrt_device.h"
@@ -31,24 +35,24 @@
 #define HRT_SP_WG 1024     // threads per workgroup (16 waves = 4 per SIMD, one workgroup per CU)
 #endif
 #define HRT_SP_SCHUNK 256  // samples per pixel traced between two ordered folds
+#define HRT_SP_NQ 6        // queues: T0 T1 S0 S1 F0 F1
 
 namespace hrtk {
 
 enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_TM, SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB,
        SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM, SP_FIELDS };
 
-struct SpCtl {           // control block in LDS
-    uint32_t cP[2], cM[2], cS[2], cF[2];  // queue fills, [parity]
+struct SpCtl {           // control block in LDS (16 dwords)
+    uint32_t cT[2], cS[2], cF[2];  // queue fills, [parity]
     uint32_t cursor;     // chunk cursor of the running cycle
     uint32_t ngen, gen_n0, paths_left;
-    uint32_t nG, nP, nM, nS;  // chunks per stage this cycle
-    uint32_t done, tile;
-    uint32_t parity, cycles;  // which queue buffers are "in"; cycles spent on the current sample chunk
+    uint32_t done, tile, parity, cycles;
+    uint32_t pad[2];
 };
 
 struct SpLds {
     uint32_t *st;        // SP_FIELDS x POOL dwords
-    uint16_t *q;         // 8 queues x POOL: P0 P1 M0 M1 S0 S1 F0 F1
+    uint16_t *q;         // HRT_SP_NQ queues x POOL
     SpCtl *ctl;
     float *run;          // 64 x 3 running pixel sums of the tile
 };
@@ -71,15 +75,39 @@ __device__ __forceinline__ void sp_push(uint16_t *q, uint32_t *count, bool want,
     if (want) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)slot;
 }
 
+__device__ __forceinline__ Ray sp_load_ray(const SpLds &L, uint32_t slot) {
+    Ray ray;
+    ray.o = mk(spf(L, SP_OX, slot), spf(L, SP_OY, slot), spf(L, SP_OZ, slot));
+    ray.d = mk(spf(L, SP_DX, slot), spf(L, SP_DY, slot), spf(L, SP_DZ, slot));
+    ray.time = spf(L, SP_TM, slot);
+    return ray;
+}
+__device__ __forceinline__ void sp_store_ray(const SpLds &L, uint32_t slot, const Ray &ray) {
+    spf(L, SP_OX, slot) = ray.o.x; spf(L, SP_OY, slot) = ray.o.y; spf(L, SP_OZ, slot) = ray.o.z;
+    spf(L, SP_DX, slot) = ray.d.x; spf(L, SP_DY, slot) = ray.d.y; spf(L, SP_DZ, slot) = ray.d.z;
+}
+__device__ __forceinline__ void sp_store_hit(const SpLds &L, uint32_t slot, const Hit &h, uint32_t pm) {
+    spu(L, SP_HID, slot) = (h.kind << 28) | h.index;
+    spf(L, SP_HT, slot) = h.t; spf(L, SP_HA0, slot) = h.a0; spf(L, SP_HA1, slot) = h.a1;
+    spu(L, SP_HTRI, slot) = h.tri; spu(L, SP_PM, slot) = pm;
+}
+__device__ __forceinline__ Hit sp_load_hit(const SpLds &L, uint32_t slot) {
+    Hit h;
+    const uint32_t hid = spu(L, SP_HID, slot);
+    h.kind = hid >> 28; h.index = hid & 0x0FFFFFFFu; h.t = spf(L, SP_HT, slot);
+    h.tri = spu(L, SP_HTRI, slot); h.a0 = spf(L, SP_HA0, slot); h.a1 = spf(L, SP_HA1, slot);
+    return h;
+}
+
 template <bool LIGHTS>
 __device__ __forceinline__ void stream_body(const DRender &R) {
     extern __shared__ uint4 s_raw[];
     SpLds L;
     L.st = reinterpret_cast<uint32_t *>(s_raw);
     L.q = reinterpret_cast<uint16_t *>(L.st + SP_FIELDS * HRT_SP_POOL);
-    L.ctl = reinterpret_cast<SpCtl *>(L.q + 8 * HRT_SP_POOL);
+    L.ctl = reinterpret_cast<SpCtl *>(L.q + HRT_SP_NQ * HRT_SP_POOL);
     L.run = reinterpret_cast<float *>(L.ctl + 1);
-    uint4 *s_units = reinterpret_cast<uint4 *>(L.run + 64 * 3 + 64);  // 16-byte aligned: all sizes above are multiples of 16
+    uint4 *s_units = reinterpret_cast<uint4 *>(L.run + 256);  // 16-byte aligned: every size above is a multiple of 16
     Ctx cx;
     cx.S = (cscene)R.scene;
     cx.lds = (lu4)s_units;
@@ -95,19 +123,18 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     }
     SpCtl &C = *L.ctl;
     if (tid == 0) {
-        C.cP[0] = C.cP[1] = C.cM[0] = C.cM[1] = C.cS[0] = C.cS[1] = 0;
+        C.cT[0] = C.cT[1] = C.cS[0] = C.cS[1] = 0;
         C.cF[0] = HRT_SP_POOL; C.cF[1] = 0;
         C.parity = 0; C.cycles = 0; C.done = 0;
     }
-    for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 3, 0)[i] = (uint16_t)i;  // every slot free
+    for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 2, 0)[i] = (uint16_t)i;  // every slot free
     const bool has_mesh = cx.S->n_meshes != 0u;
     float *scratch = R.sp_scratch + (size_t)blockIdx.x * (64u * HRT_SP_SCHUNK * 3u);
-    // Every control value is read from LDS after a barrier and made an SGPR with readfirstlane, so the
-    // compiler sees provably wave-uniform loops around the barriers (no per-lane exec juggling).
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 #ifdef HRT_SP_DEBUG
-    if (tid == 0 && blockIdx.x == 0 && R.stamps) { R.stamps[7] = 123ull; R.stamps[8] = R.tiles_owned; R.stamps[9] = R.spp; R.stamps[10] = (unsigned long long)cx.lds_n; }
+    unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0;
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
 #endif
     for (;;) {  // tiles
         __syncthreads();
@@ -125,80 +152,95 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             if (tid == 0) { C.paths_left = 64u * ns; C.gen_n0 = 0; C.cycles = 0; }
             for (;;) {  // cycles
                 __syncthreads();
+#ifdef HRT_SP_DEBUG
+                const unsigned long long dbg_s0 = __builtin_readcyclecounter();
+#endif
                 if (tid == 0) {
-                    const uint32_t parity = C.parity;
-                    const uint32_t ngen = min(C.cF[parity], C.paths_left);
+                    const uint32_t par = C.parity;
+                    const uint32_t ngen = min(C.cF[par], C.paths_left);
                     C.ngen = ngen;
-                    C.nG = (ngen + 63u) >> 6; C.nP = (C.cP[parity] + 63u) >> 6;
-                    C.nM = (C.cM[parity] + 63u) >> 6; C.nS = (C.cS[parity] + 63u) >> 6;
                     C.cursor = 0;
-                    C.cP[parity ^ 1u] = 0; C.cM[parity ^ 1u] = 0; C.cS[parity ^ 1u] = 0;
-                    C.cF[parity ^ 1u] = C.cF[parity] - ngen;  // the unused free slots carry over, SHADE appends after them
-                    C.done = (ngen == 0u && C.cP[parity] == 0u && C.cM[parity] == 0u && C.cS[parity] == 0u) ? 1u : 0u;
-                    if (++C.cycles > (1u << 16)) {  // bounded: a scheduling bug must not spin the GPU forever; the host reports it
+                    C.cT[par ^ 1u] = 0; C.cS[par ^ 1u] = 0;
+                    C.cF[par ^ 1u] = C.cF[par] - ngen;  // the unused free slots carry over, S appends after them
+                    C.done = (ngen == 0u && C.cT[par] == 0u && C.cS[par] == 0u) ? 1u : 0u;
+                    if (++C.cycles > (1u << 16)) {  // bounded: a scheduling bug must not spin the GPU; the host reports it
                         if (R.stamps) R.stamps[15] = 0xDEADull;
                         C.done = 1u;
                     }
                 }
                 __syncthreads();
-#ifdef HRT_SP_DEBUG
-                if (tid == 0 && R.stamps && blockIdx.x == 0) { atomicAdd(R.stamps + 0, 1ull); atomicAdd(R.stamps + 1, (unsigned long long)C.ngen);
-                    atomicAdd(R.stamps + 2, (unsigned long long)C.cP[C.parity]); atomicAdd(R.stamps + 3, (unsigned long long)C.cM[C.parity]);
-                    atomicAdd(R.stamps + 4, (unsigned long long)C.cS[C.parity]); atomicAdd(R.stamps + 5, (unsigned long long)C.done); }
-#endif
                 if (SP_UNI(C.done)) break;
                 const uint32_t parity = SP_UNI(C.parity);
                 const uint32_t ngen = SP_UNI(C.ngen), cFin = SP_UNI(C.cF[parity]), n0 = SP_UNI(C.gen_n0);
-                const uint32_t cPin = SP_UNI(C.cP[parity]), cMin = SP_UNI(C.cM[parity]), cSin = SP_UNI(C.cS[parity]);
-                const uint32_t nM = SP_UNI(C.nM), nS = SP_UNI(C.nS), nP = SP_UNI(C.nP), total = nM + nS + nP + SP_UNI(C.nG);
-                uint16_t *qPi = spq(L, 0, parity), *qPo = spq(L, 0, parity ^ 1u);
-                uint16_t *qMi = spq(L, 1, parity), *qMo = spq(L, 1, parity ^ 1u);
-                uint16_t *qSi = spq(L, 2, parity), *qSo = spq(L, 2, parity ^ 1u);
-                uint16_t *qFi = spq(L, 3, parity), *qFo = spq(L, 3, parity ^ 1u);
+                const uint32_t cTin = SP_UNI(C.cT[parity]), cSin = SP_UNI(C.cS[parity]);
+                const uint32_t nT = (cTin + 63u) >> 6, nS = (cSin + 63u) >> 6, nG = (ngen + 63u) >> 6, total = nT + nS + nG;
+                uint16_t *qTi = spq(L, 0, parity), *qTo = spq(L, 0, parity ^ 1u);
+                uint16_t *qSi = spq(L, 1, parity), *qSo = spq(L, 1, parity ^ 1u);
+                uint16_t *qFi = spq(L, 2, parity), *qFo = spq(L, 2, parity ^ 1u);
+                uint32_t *cTo = &C.cT[parity ^ 1u], *cSo = &C.cS[parity ^ 1u], *cFo = &C.cF[parity ^ 1u];
                 for (uint32_t i = tid; i < cFin - ngen; i += HRT_SP_WG) qFo[i] = qFi[ngen + i];  // carry unused free slots
+#ifdef HRT_SP_DEBUG
+                const unsigned long long dbg_w0 = __builtin_readcyclecounter();
+                dbg_serial += dbg_w0 - dbg_s0; ++dbg_cycles;
+#endif
 
-                for (;;) {  // chunks of this cycle: MESH first (longest), then SHADE, PRIMS, GEN
+                for (;;) {  // chunks of this cycle: T first (longest), then S, then G
                     uint32_t c = 0;
                     if (lane == 0) c = atomicAdd(&C.cursor, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
+                    c = SP_UNI(c);
                     if (c >= total) break;
-                    if (c < nM) {
-                        // ---------------- MESH
+#ifdef HRT_SP_DEBUG
+                    ++dbg_chunks;
+#endif
+                    if (c < nT) {
+                        // ---------------- T: mesh walk
                         const uint32_t e = c * 64u + lane;
-                        const bool act = e < cMin;
+                        const bool act = e < cTin;
                         uint32_t slot = 0;
                         if (act) {
-                            slot = qMi[e] & (HRT_SP_POOL - 1u);
-                            Ray ray;
-                            ray.o = mk(spf(L, SP_OX, slot), spf(L, SP_OY, slot), spf(L, SP_OZ, slot));
-                            ray.d = mk(spf(L, SP_DX, slot), spf(L, SP_DY, slot), spf(L, SP_DZ, slot));
-                            ray.time = spf(L, SP_TM, slot);
-                            Hit h;
-                            const uint32_t hid = spu(L, SP_HID, slot);
-                            h.kind = hid >> 28; h.index = hid & 0x0FFFFFFFu; h.t = spf(L, SP_HT, slot);
-                            h.tri = 0; h.a0 = spf(L, SP_HA0, slot); h.a1 = spf(L, SP_HA1, slot);
+                            slot = qTi[e] & (HRT_SP_POOL - 1u);
+                            const Ray ray = sp_load_ray(L, slot);
+                            Hit h = sp_load_hit(L, slot);
                             meshes_hit(cx, ray, spu(L, SP_PM, slot), h);
-                            spu(L, SP_HID, slot) = (h.kind << 28) | h.index;
-                            spf(L, SP_HT, slot) = h.t; spf(L, SP_HA0, slot) = h.a0; spf(L, SP_HA1, slot) = h.a1;
-                            spu(L, SP_HTRI, slot) = h.tri;
+                            sp_store_hit(L, slot, h, 0u);
                         }
-                        sp_push(qSo, &C.cS[parity ^ 1u], act, slot);
-                    } else if (c < nM + nS) {
-                        // ---------------- SHADE
-                        const uint32_t e = (c - nM) * 64u + lane;
-                        const bool act = e < cSin;
+                        sp_push(qSo, cSo, act, slot);
+                    } else {
+                        // ---------------- S (shade + scatter, then next prims) and G (camera ray, then prims)
+                        const bool is_gen = c >= nT + nS;
+                        const uint32_t e = (is_gen ? c - nT - nS : c - nT) * 64u + lane;
+                        const bool act = e < (is_gen ? ngen : cSin);
                         uint32_t slot = 0;
-                        bool again = false, freed = false;
-                        if (act) {
+                        bool trace = false, freed = false;  // trace: the path has a new ray to intersect
+                        Ray ray;
+                        ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
+                        if (act && is_gen) {
+                            slot = qFi[e] & (HRT_SP_POOL - 1u);
+                            const uint32_t n = n0 + e;  // path n of the chunk = (sample n / 64, pixel n % 64)
+                            const uint32_t p = n & 63u, s = s0 + (n >> 6);
+                            const uint32_t px = tx0 + (p & 7u), py = ty0 + (p >> 3);
+                            if (px < R.w && py < R.h) {
+                                Rng rng;
+                                rng.start(R.seed_lo, R.seed_hi, py * R.w + px, s);
+                                const float u = ((float)px + rng.next()) / (float)R.w;
+                                const float v = ((float)py + rng.next()) / (float)R.h;
+                                const float tm = rng.next();
+                                ray = camera_ray(cam, u, v, tm);
+                                spf(L, SP_TM, slot) = tm;
+                                spf(L, SP_TR, slot) = 1.f; spf(L, SP_TG, slot) = 1.f; spf(L, SP_TB, slot) = 1.f;
+                                spf(L, SP_RR, slot) = 0.f; spf(L, SP_RG, slot) = 0.f; spf(L, SP_RB, slot) = 0.f;
+                                spu(L, SP_K0, slot) = rng.k0; spu(L, SP_K1, slot) = rng.k1; spu(L, SP_RI, slot) = rng.i;
+                                spu(L, SP_N, slot) = n; spu(L, SP_REM, slot) = 6u;  // MAXBOUNCES
+                                trace = true;
+                            } else {  // pixel outside a ragged image: the sample is zero, the slot stays free
+                                float *o = scratch + (size_t)n * 3u;
+                                o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+                                freed = true;
+                            }
+                        } else if (act) {
                             slot = qSi[e] & (HRT_SP_POOL - 1u);
-                            Ray ray;
-                            ray.o = mk(spf(L, SP_OX, slot), spf(L, SP_OY, slot), spf(L, SP_OZ, slot));
-                            ray.d = mk(spf(L, SP_DX, slot), spf(L, SP_DY, slot), spf(L, SP_DZ, slot));
-                            ray.time = spf(L, SP_TM, slot);
-                            Hit h;
-                            const uint32_t hid = spu(L, SP_HID, slot);
-                            h.kind = hid >> 28; h.index = hid & 0x0FFFFFFFu; h.t = spf(L, SP_HT, slot);
-                            h.tri = spu(L, SP_HTRI, slot); h.a0 = spf(L, SP_HA0, slot); h.a1 = spf(L, SP_HA1, slot);
+                            ray = sp_load_ray(L, slot);
+                            const Hit h = sp_load_hit(L, slot);
                             f3 thr = mk(spf(L, SP_TR, slot), spf(L, SP_TG, slot), spf(L, SP_TB, slot));
                             f3 rad = mk(spf(L, SP_RR, slot), spf(L, SP_RG, slot), spf(L, SP_RB, slot));
                             int remaining = (int)spu(L, SP_REM, slot);
@@ -218,97 +260,41 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 --remaining;
                                 ended = (remaining == 0);
                                 if (!ended) {
-                                    spf(L, SP_OX, slot) = ray.o.x; spf(L, SP_OY, slot) = ray.o.y; spf(L, SP_OZ, slot) = ray.o.z;
-                                    spf(L, SP_DX, slot) = ray.d.x; spf(L, SP_DY, slot) = ray.d.y; spf(L, SP_DZ, slot) = ray.d.z;
                                     spf(L, SP_TR, slot) = thr.x; spf(L, SP_TG, slot) = thr.y; spf(L, SP_TB, slot) = thr.z;
                                     spf(L, SP_RR, slot) = rad.x; spf(L, SP_RG, slot) = rad.y; spf(L, SP_RB, slot) = rad.z;
                                     spu(L, SP_RI, slot) = rng.i;
                                     spu(L, SP_REM, slot) = (uint32_t)remaining;
+                                    trace = true;
                                 }
                             }
                             if (ended) {  // Scene.h:348: the sample's colour, parked until the ordered fold
-#ifdef HRT_SP_DEBUG
-                                if (R.stamps) atomicAdd(R.stamps + 6, 1ull);
-#endif
-                                const uint32_t n = min(spu(L, SP_N, slot), 64u * HRT_SP_SCHUNK - 1u);  // stays inside the scratch whatever happens
+                                const uint32_t n = min(spu(L, SP_N, slot), 64u * HRT_SP_SCHUNK - 1u);  // stays inside the scratch
                                 float *o = scratch + (size_t)n * 3u;
                                 o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
                                 freed = true;
-                            } else {
-                                again = true;
                             }
                         }
-                        sp_push(qPo, &C.cP[parity ^ 1u], again, slot);
-                        sp_push(qFo, &C.cF[parity ^ 1u], freed, slot);
-                    } else if (c < nM + nS + nP) {
-                        // ---------------- PRIMS
-                        const uint32_t e = (c - nM - nS) * 64u + lane;
-                        const bool act = e < cPin;
-                        uint32_t slot = 0;
+                        // spheres + squares + mesh gates for every lane of the chunk that has a new ray
                         bool to_mesh = false;
-                        if (act) {
-                            slot = qPi[e] & (HRT_SP_POOL - 1u);
-                            Ray ray;
-                            ray.o = mk(spf(L, SP_OX, slot), spf(L, SP_OY, slot), spf(L, SP_OZ, slot));
-                            ray.d = mk(spf(L, SP_DX, slot), spf(L, SP_DY, slot), spf(L, SP_DZ, slot));
-                            ray.time = spf(L, SP_TM, slot);
+                        if (trace) {
                             const Hit h = prims_hit(cx, ray);
                             const uint32_t pm = has_mesh ? mesh_gates(cx, ray) : 0u;
-                            spu(L, SP_HID, slot) = (h.kind << 28) | h.index;
-                            spf(L, SP_HT, slot) = h.t; spf(L, SP_HA0, slot) = h.a0; spf(L, SP_HA1, slot) = h.a1;
-                            spu(L, SP_HTRI, slot) = 0u; spu(L, SP_PM, slot) = pm;
+                            sp_store_ray(L, slot, ray);
+                            sp_store_hit(L, slot, h, pm);
                             to_mesh = pm != 0u;
                         }
-                        sp_push(qMo, &C.cM[parity ^ 1u], act && to_mesh, slot);
-                        sp_push(qSo, &C.cS[parity ^ 1u], act && !to_mesh, slot);
-                    } else {
-                        // ---------------- GEN: path n of the chunk = (sample n / 64, pixel n % 64)
-                        const uint32_t e = (c - nM - nS - nP) * 64u + lane;
-                        const bool act = e < ngen;
-                        uint32_t slot = 0;
-                        bool started = false, freed = false;
-                        if (act) {
-                            slot = qFi[e] & (HRT_SP_POOL - 1u);
-                            const uint32_t n = n0 + e;
-                            const uint32_t p = n & 63u, s = s0 + (n >> 6);
-                            const uint32_t px = tx0 + (p & 7u), py = ty0 + (p >> 3);
-                            if (px < R.w && py < R.h) {
-                                Rng rng;
-                                rng.start(R.seed_lo, R.seed_hi, py * R.w + px, s);
-                                const float u = ((float)px + rng.next()) / (float)R.w;
-                                const float v = ((float)py + rng.next()) / (float)R.h;
-                                const float tm = rng.next();
-                                const Ray ray = camera_ray(cam, u, v, tm);
-                                spf(L, SP_OX, slot) = ray.o.x; spf(L, SP_OY, slot) = ray.o.y; spf(L, SP_OZ, slot) = ray.o.z;
-                                spf(L, SP_DX, slot) = ray.d.x; spf(L, SP_DY, slot) = ray.d.y; spf(L, SP_DZ, slot) = ray.d.z;
-                                spf(L, SP_TM, slot) = tm;
-                                spf(L, SP_TR, slot) = 1.f; spf(L, SP_TG, slot) = 1.f; spf(L, SP_TB, slot) = 1.f;
-                                spf(L, SP_RR, slot) = 0.f; spf(L, SP_RG, slot) = 0.f; spf(L, SP_RB, slot) = 0.f;
-                                spu(L, SP_K0, slot) = rng.k0; spu(L, SP_K1, slot) = rng.k1; spu(L, SP_RI, slot) = rng.i;
-                                spu(L, SP_N, slot) = n; spu(L, SP_REM, slot) = 6u;  // MAXBOUNCES
-                                started = true;
-                            } else {  // pixel outside a ragged image: the sample is zero, the slot stays free
-                                float *o = scratch + (size_t)n * 3u;
-                                o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
-                                freed = true;
-                            }
-                        }
-                        sp_push(qPo, &C.cP[parity ^ 1u], started, slot);
-                        sp_push(qFo, &C.cF[parity ^ 1u], freed, slot);
+                        sp_push(qTo, cTo, trace && to_mesh, slot);
+                        sp_push(qSo, cSo, trace && !to_mesh, slot);
+                        sp_push(qFo, cFo, freed, slot);
                     }
                 }
-                __syncthreads();
 #ifdef HRT_SP_DEBUG
-                if (tid == 0 && blockIdx.x == 0 && R.stamps && C.cycles == 1u) {  // snapshot after the first cycle
-                    R.stamps[7] = C.cP[0]; R.stamps[8] = C.cP[1]; R.stamps[9] = C.cF[0]; R.stamps[10] = C.cF[1];
-                    R.stamps[11] = parity; R.stamps[12] = ngen; R.stamps[13] = total; R.stamps[14] = C.cursor;
-                }
+                dbg_work += __builtin_readcyclecounter() - dbg_w0;
 #endif
+                __syncthreads();
                 if (tid == 0) { C.paths_left -= ngen; C.gen_n0 += ngen; C.parity = parity ^ 1u; }
             }
-            // the chunk has drained: fold its samples into the pixel sums in sample order (main.cpp:193).
-            // The scratch was written by this workgroup's own waves on this CU; the barrier above orders it.
-            __threadfence_block();
+            // the chunk has drained: fold its samples into the pixel sums in sample order (main.cpp:193)
             __syncthreads();
             if (tid < 192) {
                 const uint32_t p = tid / 3u, ch = tid % 3u;
@@ -329,6 +315,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             R.out_tiles[(size_t)j * 192u + tid] = c;
         }
     }
+#ifdef HRT_SP_DEBUG
+    if (lane == 0 && R.stamps) {  // per-wave sums: [0] clocks in chunk loops, [1] clocks alive, [2] cycles, [3] chunks, [4] clocks in the serial section
+        atomicAdd(R.stamps + 0, dbg_work); atomicAdd(R.stamps + 1, __builtin_readcyclecounter() - dbg_t0);
+        atomicAdd(R.stamps + 2, dbg_cycles); atomicAdd(R.stamps + 3, dbg_chunks); atomicAdd(R.stamps + 4, dbg_serial);
+    }
+#endif
+#undef SP_UNI
 }
 
 }  // namespace hrtk

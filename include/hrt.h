@@ -159,7 +159,8 @@ typedef struct hrt_camera {
 enum {
     HRT_FLAG_GAMMA = 1u,       /* apply pow(c,1/2.2) (main.cpp:196)             */
     HRT_FLAG_NO_LDS_TREE = 2u, /* debug: fetch every nodelet from global memory */
-    HRT_FLAG_WAVE_KERNEL = 4u  /* use the lane-per-pixel kernel instead of the workgroup-streaming one */
+    HRT_FLAG_WAVE_KERNEL = 4u, /* force the one-pixel-per-lane kernel (default: two pixel streams per lane when the scene has meshes) */
+    HRT_FLAG_STREAM_KERNEL = 8u /* force the experimental workgroup-streaming kernel; all three give identical pixels */
 };
 
 typedef struct hrt_stats {

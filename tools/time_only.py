@@ -11,6 +11,7 @@ scenes = sys.argv[1:] or ["cornell_mesh", "random_spheres"]
 for name in scenes:
     w, h = 1920, 1080
     spp = {"cornell_mesh": 32, "random_spheres": 8, "mesh_in_box": 32, "cornell_box": 32, "backrooms_pool": 16}.get(name, 16)
+    if os.environ.get("HRT_SPP"): spp = int(os.environ["HRT_SPP"])
     s = hrt.HostScene().setup(name, w / h, 1)
     if os.environ.get('HRT_KD_LEAF'): s.set_kd_params(int(os.environ['HRT_KD_LEAF']), int(os.environ.get('HRT_KD_DEPTH', '0')))
     d = s.flatten(); cam = hrt.default_camera(w / h)
@@ -32,4 +33,5 @@ for name in scenes:
     if sum(st16):
         names = ["regen", "spheres", "quad_filter", "quad_refine", "gates", "mesh_stage", "shade", "direct", "scatter", "end", "tile_io"]
         print("   stamps %: " + "  ".join(f"{n} {100*st16[i]/tot:.1f}" for i, n in enumerate(names)), flush=True)
+        print("   raw stamps: " + " ".join(str(int(x)) for x in st16), flush=True)
     print(f"{tag:28s} {name:15s} {w}x{h}@{spp}: min {ms.min():8.2f} ms  med {np.median(ms):8.2f} ms -> {w*h*spp/ms.min()/1e3:8.1f} Msamples/s  vgpr {st.vgprs} waves {st.waves_launched} lds {st.lds_bytes}  bad_px {bad*100:.3f}%", flush=True)
