@@ -227,6 +227,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
+    cx.flags = R.flags;
     ccam cam = (ccam)R.cam;
     uint32_t *sb = reinterpret_cast<uint32_t *>(s_units + R.lds_units);  // HRT_DS_FIELDS x HRT_WG dwords
     {

@@ -147,6 +147,7 @@ struct Ctx {
     lu4 lds;         // nodelets staged in LDS
     uint32_t lds_n;  // how many
     float err_abs;   // margin scale of the filters
+    uint32_t flags;  // HRT_FLAG_* of this launch
     unsigned long long *st;  // diagnostic stamps (HRT_STAMPS builds), else unused
 };
 
@@ -452,19 +453,53 @@ __device__ __forceinline__ Hit closest_hit(const Ctx &cx, const Ray &ray) {
     return h;
 }
 
+// Every shadow ray of one shading point runs from p (plus 1e-5 along the ray) to a point within `reach` of the
+// light centre, so it stays inside the capsule of radius `reach` around the segment [p, lpos].  A sphere whose
+// centre is farther than radius + reach from that segment cannot give any of those rays a root, and the
+// reference's loop would skip it without a draw.  Bit g of the result = some sphere of group g (gsize
+// consecutive spheres) may be touched.  The test is a FILTER: its margin covers (a) its own fp32 error
+// (perpendicular-vector form, no cancellation) and (b) the error of the exact test's discriminant, which
+// cancels |oc|^2-sized terms (<= ~1e-6 |oc|^2 absolute; the margin allows 1e-5 |oc|^2).
+__device__ __forceinline__ uint64_t shadow_sphere_groups(cscene S, f3 p, f3 lpos, float reach, float time, uint32_t gsize) {
+    cf4 sph = (cf4)S->spheres;
+    const uint32_t ns = S->n_spheres;
+    const f3 ax = lpos - p;
+    const float len2 = dot(ax, ax);
+    const float inv_len2 = len2 > 0.f ? 1.f / len2 : 0.f;
+    uint64_t groups = 0ull;
+    uint32_t g = 0, in_group = 0;
+    for (uint32_t i = 0; i < ns; ++i) {  // wave-uniform: scalar rows
+        const float4 r0 = ld(sph, 2 * i), r1 = ld(sph, 2 * i + 1);
+        const f3 v = (mk(r0) + time * mk(r1)) - p;
+        const float s = fminf(fmaxf(dot(v, ax) * inv_len2, 0.f), 1.f);
+        const f3 w = v - s * ax;
+        const float R = fabsf(r0.w) + reach;
+        const float lim = R * R * 1.01f + 1e-5f * (1.f + dot(v, v) + len2);
+        if (dot(w, w) <= lim) groups |= 1ull << g;
+        if (++in_group == gsize) { in_group = 0; ++g; }
+    }
+    return groups;
+}
+
 // Scene::computeShadow, Scene.h:235-255: candidates in object order, each lets the ray
 // through with probability `transparency` (one draw per candidate).
-__device__ __forceinline__ bool shadow_blocked(const Ctx &cx, const Ray &ray, float tmax, Rng &rng) {
+// Only the sphere groups in `groups` are tested (shadow_sphere_groups: no other sphere can be reached),
+// in ascending index order, so the draws fall exactly where the reference's full loop puts them.
+__device__ __forceinline__ bool shadow_blocked(const Ctx &cx, const Ray &ray, float tmax, Rng &rng, uint64_t groups, uint32_t gsize) {
     cscene S = cx.S;
-    cf4 sph = (cf4)S->spheres;
+    gf4 sph = (gf4)S->spheres;
     gf4 mats = (gf4)S->materials;
     const uint32_t ns = S->n_spheres;
-    for (uint32_t i = 0; i < ns; ++i) {
-        float t;
-        const float4 r1 = ld(sph, 2 * i + 1);
-        if (sphere_t(ld(sph, 2 * i), r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
-            const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(r1.w)).w;
-            if (rng.next() > transparency) return true;
+    while (groups) {
+        const uint32_t i0 = (uint32_t)__builtin_ctzll(groups) * gsize, i1 = min(i0 + gsize, ns);
+        groups &= groups - 1ull;
+        for (uint32_t i = i0; i < i1; ++i) {
+            float t;
+            const float4 r1 = ld(sph, 2 * i + 1);
+            if (sphere_t(ld(sph, 2 * i), r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
+                const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(r1.w)).w;
+                if (rng.next() > transparency) return true;
+            }
         }
     }
     cf4 qd = (cf4)S->quads;
@@ -684,6 +719,10 @@ __device__ __forceinline__ f3 direct_light(const Ctx &cx, const Surface &sf, con
         color = color + ((mk(ld(L, 1)) * sf.albedo) * fmaxf(0.0f, dotLN)) * (float)(1. - (double)sf.transparency);  // lights[0] (N2)
         int blocked = 0;
         const float delta = l0.w / 2.f;
+        const uint32_t gsize = (cx.S->n_spheres + 63u) / 64u;
+        const uint64_t groups = (cx.flags & HRT_FLAG_NO_SHADOW_CULL)
+                                    ? ~0ull  // every group: the reference's full loop (tests compare the two bit for bit)
+                                    : shadow_sphere_groups(cx.S, sf.p, lpos, fabsf(delta) * 1.0001f + 1e-6f, ray.time, gsize);
         for (int j = 0; j < 10; ++j) {  // NB_ECH
             const f3 lp = lpos + rng.unit_vector() * delta;
             const f3 to = lp - sf.p;
@@ -693,7 +732,7 @@ __device__ __forceinline__ f3 direct_light(const Ctx &cx, const Surface &sf, con
             sr.o = sf.p + Ls * HRT_EPS;
             sr.d = normalize(Ls);
             sr.time = ray.time;
-            if (shadow_blocked(cx, sr, tLight, rng)) blocked++;
+            if (shadow_blocked(cx, sr, tLight, rng, groups, gsize)) blocked++;
         }
         const float shadow = (float)(1. - (double)((float)blocked / 10.f));
         color = color * shadow;  // the running sum, earlier lights included (N3)
@@ -746,6 +785,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
+    cx.flags = R.flags;
     ccam cam = (ccam)R.cam;
     {
         gu4 g_units = (gu4)cx.S->kd_units;
@@ -906,6 +946,7 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
     cx.lds = (lu4) nullptr;
     cx.lds_n = 0;  // every nodelet from global memory here
     cx.err_abs = R.err_abs;
+    cx.flags = R.flags;
     unsigned long long stamps_local[17] = {0};
     cx.st = stamps_local;
     const Ray ray = camera_ray((ccam)R.cam, ((float)x + 0.5f) / (float)R.w, ((float)y + 0.5f) / (float)R.h, 0.f);

@@ -113,6 +113,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
+    cx.flags = R.flags;
     unsigned long long stamps_local[17];
     cx.st = stamps_local;
     ccam cam = (ccam)R.cam;
