@@ -29,6 +29,15 @@
 #ifndef HRT_DS_TRIPS
 #define HRT_DS_TRIPS 8     // KD-walk trips per stage B visit; an unfinished walk resumes at the next visit
 #endif
+#ifndef HRT_WALK_LEVELS
+#define HRT_WALK_LEVELS 3  // inner nodes descended per trip (A/B on MI355X, Cornell+mesh / mesh_in_box: 1 -> 48.3 / 59.8 ms, 2 -> 44.2 / 54.6, 3 -> 43.5 / 53.0, 4 -> 43.6 / 52.7)
+#endif
+#ifndef HRT_WALK_SPEC
+#define HRT_WALK_SPEC 0    // 1: request all five rows of a triangle at once (one latency, more loads)
+#endif
+#ifndef HRT_WALK_ROPES
+#define HRT_WALK_ROPES 0   // 1: request the rope nodelets together with the leaf header
+#endif
 #define HRT_DS_FIELDS 34   // dwords of one backed-up stream
 #define HRT_DS_NONE 0xFFFFFFFFu
 
@@ -138,7 +147,7 @@ __device__ __forceinline__ bool mesh_walk(const Ctx &cx, cmesh M, const Ray &ray
     f3 p = ray.o + t_entry * ray.d;
     for (int trip = 0; trip < trips && ref != HRT_KD_NIL; ++trip) {
 #pragma unroll
-        for (int lvl = 0; lvl < 2; ++lvl) {
+        for (int lvl = 0; lvl < HRT_WALK_LEVELS; ++lvl) {
             if (!(ref & HRT_KD_LEAF)) {
                 const uint4 nd = kd_fetch(g_units, cx, ref);
                 const float split = __uint_as_float(nd.x);
@@ -151,17 +160,25 @@ __device__ __forceinline__ bool mesh_walk(const Ctx &cx, cmesh M, const Ray &ray
             const uint32_t lu = ref & ~HRT_KD_LEAF;
             const uint4 l0 = kd_fetch(g_units, cx, lu);
             const uint4 l1 = kd_fetch(g_units, cx, lu + 1);
+#if HRT_WALK_ROPES
+            const uint4 rp0 = kd_fetch(g_units, cx, lu + 2), rp1 = kd_fetch(g_units, cx, lu + 3);
+#endif
             const uint32_t first = tri_base + l0.w, cnt = l1.w;
             if (k == 0xFFFFu) k = 0;
             if (k < cnt) {
                 gf4 tr = tris + HRT_TRI_ROWS * (first + k);
                 const float4 r3 = ld(tr, 3);
+#if HRT_WALK_SPEC
+                const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
+#endif
                 const f3 n = mk(r3);
                 const float dotRN = dot(ray.d, n);
                 if (dotRN < 0.f) {                                     // Triangle.h:80-91: else parallel / back-facing (NaN: no hit)
                     const float t = (r3.w - dot(ray.o, n)) / dotRN;    // :95
                     if (!(t < 0.f) && t < w.best_t) {                  // :96, then the leaf's strict `<` (KDTree.cpp:44)
+#if !HRT_WALK_SPEC
                         const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
+#endif
                         const f3 v2 = (ray.o + t * ray.d) - mk(r0);
                         const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
                         const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;  // Triangle.h:72-74
@@ -188,7 +205,11 @@ __device__ __forceinline__ bool mesh_walk(const Ctx &cx, cmesh M, const Ray &ray
                 } else {
                     t_entry = fmaxf(t_entry, t_exit);
                     p = ray.o + t_entry * ray.d;
+#if HRT_WALK_ROPES
+                    const uint4 rp = (face >> 2) ? rp1 : rp0;
+#else
                     const uint4 rp = kd_fetch(g_units, cx, lu + 2 + (face >> 2));
+#endif
                     const uint32_t sel = face & 3u;
                     ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
                     k = 0xFFFFu;
