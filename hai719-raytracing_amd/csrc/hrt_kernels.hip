@@ -37,6 +37,12 @@
 #ifndef HRT_MIN_WAVES
 #define HRT_MIN_WAVES 4    // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef HRT_MIN_WAVES_SINGLE
+#define HRT_MIN_WAVES_SINGLE 5         // hrt_trace_kernel: 96 VGPRs; A/B on MI355X, Cornell box 1080p@32: 4 -> 20.1 ms, 5 -> 18.4, 6 -> 19.2, 8 -> 20.9
+#endif
+#ifndef HRT_MIN_WAVES_SINGLE_LIGHTS
+#define HRT_MIN_WAVES_SINGLE_LIGHTS 5  // hrt_trace_kernel_lights: random_spheres 1080p@8: 4 -> 8.02 ms, 5 -> 7.70, 6 -> 8.09, 8 -> 9.33
+#endif
 
 namespace hrtk {
 
@@ -910,8 +916,8 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
 
 using namespace hrtk;
 
-extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES) hrt_trace_kernel(const DRender R) { trace_body<false>(R); }
-extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES) hrt_trace_kernel_lights(const DRender R) { trace_body<true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES_SINGLE) hrt_trace_kernel(const DRender R) { trace_body<false>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES_SINGLE_LIGHTS) hrt_trace_kernel_lights(const DRender R) { trace_body<true>(R); }
 
 // gamma_correct (Functions.cpp:56-60): pow(c, 1/2.2) in double, over this rank's tile buffer.  Kept out of
 // the megakernel: fp64 pow is register-hungry and runs once per pixel.
