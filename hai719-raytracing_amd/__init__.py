@@ -152,6 +152,11 @@ def device_lib() -> C.CDLL:
         lib.hrt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.hrt_kernel_info.argtypes = [C.POINTER(Stats)]
         lib.hrt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.hrt_render_accumulate.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.hrt_finalize_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.hrt_encode_ppm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.c_void_p]
         _dev = lib
     return _dev
 
@@ -301,6 +306,12 @@ class DeviceScene:
         self._check(self._lib.hrt_render_tiles(self._h, C.byref(cam), w, h, spp, seed, flags, rank, world,
                                                C.c_void_p(d_tiles_ptr), C.c_void_p(stream_ptr)))
 
+    def render_accumulate(self, cam: Camera, w: int, h: int, first_sample: int, n_samples: int, seed: int, flags: int,
+                          rank: int, world: int, d_sum_tiles_ptr: int, stream_ptr: int = 0):
+        """hrt_render_accumulate: add samples [first_sample, first_sample + n_samples) to the running sums (asynchronous)."""
+        self._check(self._lib.hrt_render_accumulate(self._h, C.byref(cam), w, h, first_sample, n_samples, seed, flags, rank,
+                                                    world, C.c_void_p(d_sum_tiles_ptr), C.c_void_p(stream_ptr)))
+
     def last_kernel_ms(self) -> float:
         ms = C.c_double()
         self._check(self._lib.hrt_last_kernel_ms(self._h, C.byref(ms)))
@@ -338,6 +349,39 @@ def assemble_frame_host(gathered: np.ndarray, w: int, h: int, world: int) -> np.
         hh, ww = min(TILE, h - y0), min(TILE, w - x0)
         frame[y0:y0 + hh, x0:x0 + ww] = tile[:hh, :ww]
     return frame
+
+
+def finalize_tiles(d_sum_tiles_ptr: int, n_tiles: int, total_samples: int, flags: int, d_tiles_ptr: int, stream_ptr: int = 0):
+    """hrt_finalize_tiles: running sums -> pixel means (+ gamma with FLAG_GAMMA); the two pointers may be equal."""
+    lib = device_lib()
+    rc = lib.hrt_finalize_tiles(C.c_void_p(d_sum_tiles_ptr), n_tiles, total_samples, flags, C.c_void_p(d_tiles_ptr),
+                                C.c_void_p(stream_ptr))
+    if rc < 0:
+        raise HrtError(f"hrt_finalize_tiles failed ({rc}): {lib.hrt_last_error().decode()}")
+
+
+def encode_ppm(d_frame_ptr: int, w: int, h: int, fmt: int, d_out_ptr: int, capacity: int, stream_ptr: int = 0) -> int:
+    """hrt_encode_ppm: the reference's PPM file (fmt 3, byte for byte) or its binary form (fmt 6), encoded on the
+    device into d_out; returns the file size in bytes."""
+    lib = device_lib()
+    n = C.c_size_t(0)
+    rc = lib.hrt_encode_ppm(C.c_void_p(d_frame_ptr), w, h, fmt, C.c_void_p(d_out_ptr), capacity, C.byref(n), C.c_void_p(stream_ptr))
+    if rc < 0:
+        raise HrtError(f"hrt_encode_ppm failed ({rc}): {lib.hrt_last_error().decode()}")
+    return int(n.value)
+
+
+def ppm_text_reference(rgb: np.ndarray) -> bytes:
+    """Host statement of main.cpp:258-262 (what `ofstream <<` writes for an (h, w, 3) float32 frame); the
+    checker of hrt_encode_ppm in the tests."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    m = np.where(rgb < np.float32(1.0), rgb, np.float32(1.0))          # std::min<float>(1.f, c): NaN -> 1
+    v = (np.float32(255.0) * m).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        iv = np.where(np.isfinite(v), np.trunc(np.clip(v, -2147483648.0, 255.0)), -2147483648.0).astype(np.int64)
+    body = " ".join(str(int(x)) for x in iv.reshape(-1))
+    return f"P3\n{w} {h}\n255\n".encode() + body.encode() + b" \n"
 
 
 def write_ppm(path: str, rgb: np.ndarray):

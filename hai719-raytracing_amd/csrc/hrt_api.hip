@@ -4,6 +4,7 @@
 #include "hrt_kernels.hip"
 #include "hrt_stream.hip"
 #include "hrt_dual.hip"
+#include "hrt_output.hip"
 
 #include <chrono>
 #include <cmath>
@@ -516,16 +517,23 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
     return HRT_OK;
 }
 
-int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
-                     uint32_t flags, uint32_t rank, uint32_t world, float *d_tiles, void *stream_) {
+// One launch of the trace kernel over this rank's tiles: samples [s0, s0 + spp) of every pixel.
+// accumulate = false: d_tiles receives the pixel means (s0 must be 0).
+// accumulate = true : d_tiles holds the running sums of samples [0, s0) and receives the sums of [0, s0 + spp).
+static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t s0, uint32_t spp, uint64_t seed,
+                        uint32_t flags, uint32_t rank, uint32_t world, float *d_tiles, void *stream_, bool accumulate) {
     DRender R;
     int rc = fill_render(s, cam, w, h, spp, seed, flags, rank, world, R, (hipStream_t)stream_);
     if (rc != HRT_OK) return rc;
-    if (!d_tiles) return fail(HRT_ERR_INVALID, "hrt_render_tiles: NULL output");
+    if (!d_tiles) return fail(HRT_ERR_INVALID, "render: NULL tile buffer");
+    if ((uint64_t)s0 + spp > 0xffffffffull) return fail(HRT_ERR_INVALID, "render: sample index overflows 32 bits");
     R.out_tiles = d_tiles;
+    R.s0 = s0;
+    R.accumulate = accumulate ? 1u : 0u;
+    if (accumulate) flags &= ~(uint32_t)(HRT_FLAG_GAMMA | HRT_FLAG_STREAM_KERNEL);  // hrt_finalize_tiles applies the gamma
     hipStream_t stream = (hipStream_t)stream_;
     if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
-    const bool stream_kernel = (g_rt.use_stream || (flags & HRT_FLAG_STREAM_KERNEL)) && !(flags & HRT_FLAG_WAVE_KERNEL);
+    const bool stream_kernel = !accumulate && (g_rt.use_stream || (flags & HRT_FLAG_STREAM_KERNEL)) && !(flags & HRT_FLAG_WAVE_KERNEL);
     const bool dual_kernel = !stream_kernel && g_rt.use_dual && s->d.n_meshes > 0u && s->max_leaf < 0xFFFFu && !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
@@ -589,6 +597,85 @@ int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h
         HIP_TRY(hipGetLastError());
     }
     s->timed = true;
+    return HRT_OK;
+}
+
+int hrt_render_tiles(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
+                     uint32_t flags, uint32_t rank, uint32_t world, float *d_tiles, void *stream) {
+    return launch_trace(s, cam, w, h, 0u, spp, seed, flags, rank, world, d_tiles, stream, false);
+}
+
+int hrt_render_accumulate(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t first_sample, uint32_t n_samples,
+                          uint64_t seed, uint32_t flags, uint32_t rank, uint32_t world, float *d_sum_tiles, void *stream) {
+    return launch_trace(s, cam, w, h, first_sample, n_samples, seed, flags, rank, world, d_sum_tiles, stream, true);
+}
+
+int hrt_finalize_tiles(const float *d_sum_tiles, uint32_t n_tiles, uint32_t total_samples, uint32_t flags, float *d_tiles,
+                       void *stream_) {
+    if (!d_sum_tiles || !d_tiles || !total_samples) return fail(HRT_ERR_INVALID, "hrt_finalize_tiles: bad argument");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_finalize_tiles: call hrt_init first");
+    if (!n_tiles) return HRT_OK;
+    const uint32_t n = n_tiles * 64u * 3u;
+    hipLaunchKernelGGL(hrt_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_sum_tiles, d_tiles, n,
+                       total_samples, (flags & HRT_FLAG_GAMMA) ? 1u : 0u);
+    HIP_TRY(hipGetLastError());
+    return HRT_OK;
+}
+
+int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, unsigned char *d_out, size_t capacity,
+                   size_t *bytes, void *stream_) {
+    if (!d_frame || !d_out || !bytes || !w || !h) return fail(HRT_ERR_INVALID, "hrt_encode_ppm: bad argument");
+    if (format != 3 && format != 6) return fail(HRT_ERR_INVALID, "hrt_encode_ppm: format must be 3 (ASCII) or 6 (binary)");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_encode_ppm: call hrt_init first");
+    if ((uint64_t)w * h > 0x7fffffffull / 16u) return fail(HRT_ERR_INVALID, "hrt_encode_ppm: image too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    char head[64];
+    // main.cpp:258: "P3" endl w " " h endl 255 endl
+    const int hl = std::snprintf(head, sizeof(head), "P%d\n%u %u\n255\n", format, w, h);
+    const uint32_t npix = w * h;
+    if (format == 6) {
+        const size_t total = (size_t)hl + (size_t)npix * 3u;
+        if (capacity < total) return fail(HRT_ERR_INVALID, "hrt_encode_ppm: output buffer too small (need " + std::to_string(total) + ")");
+        HIP_TRY(hipMemcpyAsync(d_out, head, (size_t)hl, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(hrt_ppm6_kernel, dim3((npix * 3u + 255u) / 256u), dim3(256), 0, stream, d_frame, npix * 3u, d_out + hl);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));  // `head` is a stack buffer
+        *bytes = total;
+        return HRT_OK;
+    }
+    // P3, byte for byte what the reference's ofstream writes (main.cpp:259-261): per pixel "r g b " with each
+    // value printed as a decimal int; pass 1 measures every pixel's text, a block scan turns lengths into
+    // offsets, pass 2 writes the digits.  Blocks of 1024 pixels; block totals are scanned on the host side of
+    // the launch (n/1024 words) to keep the device code to two simple kernels.
+    const uint32_t nblocks = (npix + 1023u) / 1024u;
+    uint32_t *d_len = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_len, ((size_t)npix + nblocks) * sizeof(uint32_t)));
+    uint32_t *d_block = d_len + npix;
+    hipLaunchKernelGGL(hrt_ppm3_measure_kernel, dim3(nblocks), dim3(256), 0, stream, d_frame, npix, d_len, d_block);
+    std::vector<uint32_t> block(nblocks);
+    hipError_t e = hipMemcpyAsync(block.data(), d_block, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { (void)hipFree(d_len); return fail(HRT_ERR_DEVICE, std::string("hrt_encode_ppm: ") + hipGetErrorString(e)); }
+    std::vector<unsigned long long> base(nblocks);
+    unsigned long long run = (unsigned long long)hl;
+    for (uint32_t b = 0; b < nblocks; ++b) { base[b] = run; run += block[b]; }
+    const size_t total = (size_t)run + 1u;  // the closing endl
+    if (capacity < total) { (void)hipFree(d_len); return fail(HRT_ERR_INVALID, "hrt_encode_ppm: output buffer too small (need " + std::to_string(total) + ")"); }
+    unsigned long long *d_base = nullptr;
+    e = hipMalloc((void **)&d_base, nblocks * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_base, base.data(), nblocks * sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_out, head, (size_t)hl, hipMemcpyHostToDevice, stream);
+    const unsigned char nl = '\n';
+    if (e == hipSuccess) e = hipMemcpyAsync(d_out + run, &nl, 1, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hrt_ppm3_write_kernel, dim3(nblocks), dim3(256), 0, stream, d_frame, npix, d_len, d_base, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_len);
+    if (d_base) (void)hipFree(d_base);
+    if (e != hipSuccess) return fail(HRT_ERR_DEVICE, std::string("hrt_encode_ppm: ") + hipGetErrorString(e));
+    *bytes = total;
     return HRT_OK;
 }
 

@@ -90,6 +90,8 @@ struct DRender {
     uint32_t flags;
     uint32_t rank, world;
     uint32_t tiles_x, tiles_total, tiles_owned;
+    uint32_t s0;               // index of the first sample of this launch (progressive rendering), else 0
+    uint32_t accumulate;       // 1: out_tiles holds running sums of samples [0, s0): add this launch's samples, store sums
     uint32_t lds_units;        // leading kd units each workgroup stages into LDS
     float err_abs;             // 2e-6 * (largest |coordinate| of scene + camera): margin of the no-division filters
     float *out_tiles;          // tiles_owned * 64 * 3 floats, tile-major

@@ -280,15 +280,23 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
         return px < R.w && py < R.h && R.spp > 0u;
     };
 
+    auto fresh = [&](PathState &q, uint32_t j, bool in) {  // a stream at the start of tile slot j
+        ds_fresh(q, in);
+        if (R.accumulate && in) {  // progressive mode: continue the running sum of samples [0, s0)
+            const float *a = R.out_tiles + ((size_t)j * 64u + lane) * 3u;
+            q.sum = mk(a[0], a[1], a[2]);
+        }
+    };
+
     tj[0] = pull();
     tj[1] = pull();
     {
         const bool in1 = locate(tj[1], pxy[1]);
-        ds_fresh(p, in1);
+        fresh(p, tj[1], in1);
         ds_store(sb, p);
         bak_fl = ds_flags(p);
         const bool in0 = locate(tj[0], pxy[0]);
-        ds_fresh(p, in0);
+        fresh(p, tj[0], in0);
     }
 
     for (;;) {
@@ -306,7 +314,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
             const uint32_t px = pxy[X] & 0xFFFFu, py = pxy[X] >> 16;
             f3 c = mk(0.f, 0.f, 0.f);
             if (px < R.w && py < R.h) {
-                const float nspp = (float)R.spp;
+                const float nspp = R.accumulate ? 1.f : (float)R.spp;  // progressive mode stores the raw sum
                 c = mk(sum.x / nspp, sum.y / nspp, sum.z / nspp);  // main.cpp:195
             }
             float *o = R.out_tiles + ((size_t)tj[X] * 64u + lane) * 3u;
@@ -314,10 +322,10 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
             tj[X] = pull();
             const bool in = locate(tj[X], pxy[X]);
             if (mine) {
-                ds_fresh(p, in);
+                fresh(p, tj[X], in);
             } else {
                 PathState q;
-                ds_fresh(q, in);
+                fresh(q, tj[X], in);
                 ds_store(sb, q);
                 bak_fl = ds_flags(q);
             }
@@ -332,7 +340,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
             if (p.remaining == 0) {  // next camera sample of this pixel (main.cpp:188-192)
                 const uint32_t xy = cur ? pxy[1] : pxy[0];
                 const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
-                p.rng.start(R.seed_lo, R.seed_hi, py * R.w + px, p.s);
+                p.rng.start(R.seed_lo, R.seed_hi, py * R.w + px, R.s0 + p.s);
                 const float u = ((float)px + p.rng.next()) / (float)R.w;
                 const float v = ((float)py + p.rng.next()) / (float)R.h;
                 const float tm = p.rng.next();

@@ -517,7 +517,11 @@ __device__ __forceinline__ bool shadow_blocked(const Ctx &cx, const Ray &ray, fl
             if (rng.next() > transparency) return true;
         }
     }
+#ifdef HRT_ABL_NO_SHADOW_MESH  // ablation only
+    const uint32_t nm = 0;
+#else
     const uint32_t nm = min(S->n_meshes, 32u);
+#endif
     if (nm) {
         const f3 inv = ray_inv(ray);
         for (uint32_t i = 0; i < nm; ++i) {
@@ -819,6 +823,10 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
         const uint32_t pixel = py * R.w + px;
 
         f3 sum = mk(0.f, 0.f, 0.f);
+        if (R.accumulate && inside) {  // progressive mode: continue the running sum of samples [0, s0)
+            const float *a = R.out_tiles + ((size_t)j * 64u + lane) * 3u;
+            sum = mk(a[0], a[1], a[2]);
+        }
         uint32_t s = 0;          // next sample of this lane's pixel
         int remaining = 0;       // bounces left on the current path; 0 = needs a new path
         Ray ray;
@@ -836,7 +844,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
             // ---- stage A: (re)generate, spheres + squares, mesh gates
             if (live && stage == 0u) {
                 if (remaining == 0) {  // next camera sample of this pixel (main.cpp:188-192)
-                    rng.start(R.seed_lo, R.seed_hi, pixel, s);
+                    rng.start(R.seed_lo, R.seed_hi, pixel, R.s0 + s);
                     const float u = ((float)px + rng.next()) / (float)R.w;
                     const float v = ((float)py + rng.next()) / (float)R.h;
                     const float tm = rng.next();
@@ -900,7 +908,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
         float *o = R.out_tiles + ((size_t)j * 64u + lane) * 3u;
         f3 c = mk(0.f, 0.f, 0.f);
         if (inside) {
-            const float nspp = (float)R.spp;
+            const float nspp = R.accumulate ? 1.f : (float)R.spp;  // progressive mode stores the raw sum (x / 1.f is exact)
             c = mk(sum.x / nspp, sum.y / nspp, sum.z / nspp);  // main.cpp:195
         }
         o[0] = c.x; o[1] = c.y; o[2] = c.z;

@@ -225,6 +225,28 @@ int hrt_debug_read_stamps(hrt_scene *scene, uint64_t out[16]);
 /* Output stage of main.cpp:252-262: P3 ASCII with (int)(255*min(1,c)). */
 int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
 
+/* ---- progressive rendering / resume (replaces the all-or-nothing sample loop main.cpp:188-195)
+ * d_sum_tiles (device, hrt_tiles_owned()*HRT_TILE^2*3 floats, zeroed by the caller before the first call) holds
+ * the running per-pixel SUMS of samples [0, first_sample); the call adds samples [first_sample, first_sample +
+ * n_samples) in sample order.  Because a sample's random numbers depend only on (seed, pixel, sample index) and
+ * the sum continues in the same order, k calls covering [0, N) leave exactly the bits one hrt_render_tiles of N
+ * samples would have summed: a render can be previewed, stopped, checkpointed (copy the buffer) and resumed.
+ * HRT_FLAG_GAMMA is ignored here; hrt_finalize_tiles applies it. */
+int hrt_render_accumulate(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
+                          uint32_t first_sample, uint32_t n_samples, uint64_t seed, uint32_t flags,
+                          uint32_t rank, uint32_t world, float *d_sum_tiles, void *stream);
+/* sums -> pixel means (`image[i] /= nsamples`, main.cpp:195) and, with HRT_FLAG_GAMMA, gamma_correct
+ * (main.cpp:196).  d_tiles may alias d_sum_tiles.  The result is what hrt_render_tiles(total_samples) writes. */
+int hrt_finalize_tiles(const float *d_sum_tiles, uint32_t n_tiles, uint32_t total_samples, uint32_t flags,
+                       float *d_tiles, void *stream);
+/* The PPM file of main.cpp:252-262 encoded ON THE DEVICE from a row-major frame (device, h*w*3 floats).
+ * format 3: the reference's ASCII file byte for byte ("P3\n<w> <h>\n255\n", then "r g b " per pixel, "\n");
+ * format 6: the same integers as bytes (binary PPM; negative values, which P3 prints with a sign, clamp to 0).
+ * d_out: device buffer of `capacity` bytes (16*w*h + 64 always suffices for non-negative frames; the call
+ * fails with the needed size otherwise); *bytes = size of the file.  Synchronises the stream. */
+int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, unsigned char *d_out,
+                   size_t capacity, size_t *bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+"""Output stage on the device: progressive accumulation / resume and the PPM encoders.
+Everything here is bit-exact: the progressive path must leave the bits of the one-shot render, and the
+encoded file must be the bytes the reference's `ofstream <<` loop writes (main.cpp:258-262)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def build(gpu, name, aspect):
+    host = gpu.HostScene().setup(name, aspect, 1)
+    desc = host.flatten()
+    return desc, gpu.DeviceScene(desc), gpu.default_camera(aspect)
+
+
+def one_shot(gpu, dev, cam, w, h, spp, seed, flags, world=1):
+    import torch
+    per = gpu.tiles_owned(w, h, 0, world)
+    gathered = torch.zeros((world, per, 64, 3), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        dev.render_tiles(cam, w, h, spp, seed, flags, r, world, gathered[r].data_ptr(), 0)
+    frame = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    gpu.assemble_frame(gathered.data_ptr(), per, w, h, world, frame.data_ptr(), 0)
+    torch.cuda.synchronize()
+    return frame
+
+
+@pytest.mark.parametrize("name,flags_name,world", [("cornell_mesh", None, 1), ("cornell_mesh", "FLAG_WAVE_KERNEL", 2),
+                                                   ("random_spheres", None, 1), ("backrooms_pool", None, 3)])
+def test_progressive_chunks_leave_the_bits_of_the_one_shot_render(gpu, name, flags_name, world):
+    """Samples added in chunks of 3 + 1 + 8 + 4 (per-pixel sums continue in sample order) == 16 spp at once,
+    with and without gamma, for both lane-per-pixel kernel forms and across tile partitions."""
+    import torch
+    w, h, seed = 120, 67, 17
+    flags = getattr(gpu, flags_name) if flags_name else 0
+    desc, dev, cam = build(gpu, name, w / h)
+    per = gpu.tiles_owned(w, h, 0, world)
+    sums = torch.zeros((world, per, 64, 3), dtype=torch.float32, device="cuda")
+    first = 0
+    for n in (3, 1, 8, 4):
+        for r in range(world):
+            dev.render_accumulate(cam, w, h, first, n, seed, flags, r, world, sums[r].data_ptr(), 0)
+        first += n
+    for gamma in (0, gpu.FLAG_GAMMA):
+        means = torch.empty_like(sums)
+        gpu.finalize_tiles(sums.data_ptr(), world * per, first, gamma, means.data_ptr(), 0)
+        frame = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        gpu.assemble_frame(means.data_ptr(), per, w, h, world, frame.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ref = one_shot(gpu, dev, cam, w, h, first, seed, flags | gamma, world)
+        assert float(ref.max()) > 0
+        assert torch.equal(frame, ref)
+
+
+def test_resume_from_a_checkpoint_on_a_fresh_scene_object(gpu):
+    """Checkpoint = the sum buffer + the number of samples done.  A new process (here: a new DeviceScene)
+    that reloads it and continues ends with the same bits as an uninterrupted render."""
+    import torch
+    w, h, seed = 64, 40, 3
+    desc, dev, cam = build(gpu, "mesh_in_box", w / h)
+    per = gpu.tiles_owned(w, h, 0, 1)
+    sums = torch.zeros((per, 64, 3), dtype=torch.float32, device="cuda")
+    dev.render_accumulate(cam, w, h, 0, 5, seed, 0, 0, 1, sums.data_ptr(), 0)
+    torch.cuda.synchronize()
+    checkpoint = sums.cpu().numpy().copy()
+    del dev
+    desc2, dev2, cam2 = build(gpu, "mesh_in_box", w / h)
+    sums2 = torch.from_numpy(checkpoint).cuda()
+    dev2.render_accumulate(cam2, w, h, 5, 6, seed, 0, 0, 1, sums2.data_ptr(), 0)
+    gpu.finalize_tiles(sums2.data_ptr(), per, 11, 0, sums2.data_ptr(), 0)  # in place
+    frame = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    gpu.assemble_frame(sums2.data_ptr(), per, w, h, 1, frame.data_ptr(), 0)
+    torch.cuda.synchronize()
+    ref, _ = dev2.render(cam2, w, h, 11, seed=seed)
+    assert np.array_equal(frame.cpu().numpy(), ref)
+
+
+def encode(gpu, frame_t, fmt):
+    import torch
+    h, w, _ = frame_t.shape
+    cap = 40 * w * h + 64
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    n = gpu.encode_ppm(frame_t.data_ptr(), w, h, fmt, out.data_ptr(), cap, 0)
+    return bytes(out[:n].cpu().numpy())
+
+
+def test_ppm_encoded_on_the_device_is_the_reference_file_byte_for_byte(gpu):
+    import torch
+    # a rendered frame (gamma-corrected, as the reference writes it) ...
+    w, h = 203, 77  # not a multiple of the 1024-pixel encoder block
+    desc, dev, cam = build(gpu, "cornell_box", w / h)
+    frame = one_shot(gpu, dev, cam, w, h, 4, 9, gpu.FLAG_GAMMA)
+    host = frame.cpu().numpy()
+    assert encode(gpu, frame, 3) == gpu.ppm_text_reference(host)
+    p6 = encode(gpu, frame, 6)
+    head = f"P6\n{w} {h}\n255\n".encode()
+    want = np.trunc(np.float32(255.0) * np.minimum(host, np.float32(1.0))).astype(np.uint8).tobytes()
+    assert p6 == head + want
+    # ... and the values a renderer should never produce but the reference's expression still defines:
+    # > 1 clamps, NaN -> 255, negatives print with a sign (P3) / clamp to 0 (P6), -inf -> INT_MIN
+    rng = np.random.default_rng(5)
+    odd = rng.uniform(-0.2, 1.3, size=(31, 45, 3)).astype(np.float32)
+    odd[0, 0] = (np.nan, -np.inf, np.inf)
+    odd[1, 1] = (-1e30, 1e30, -0.0)
+    odd[2, 2] = (0.999999, 1.0 / 255.0, 0.00392156)
+    t = torch.from_numpy(odd).cuda()
+    assert encode(gpu, t, 3) == gpu.ppm_text_reference(odd)
+    p6 = encode(gpu, t, 6)
+    m = np.where(odd < 1, odd, np.float32(1.0))
+    v = np.float32(255.0) * m
+    want = np.where(np.isfinite(v), np.clip(np.trunc(v), 0, 255), 0).astype(np.uint8).tobytes()
+    assert p6 == f"P6\n45 31\n255\n".encode() + want
+
+
+def test_encoder_rejects_a_buffer_that_is_too_small(gpu):
+    import torch
+    t = torch.full((4, 4, 3), 0.5, dtype=torch.float32, device="cuda")
+    out = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(gpu.HrtError, match="too small"):
+        gpu.encode_ppm(t.data_ptr(), 4, 4, 3, out.data_ptr(), 16, 0)
+    with pytest.raises(gpu.HrtError):
+        gpu.encode_ppm(t.data_ptr(), 4, 4, 5, out.data_ptr(), 16, 0)
