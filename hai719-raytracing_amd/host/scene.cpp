@@ -333,6 +333,15 @@ bool Scene::setup_by_name(const std::string &name, float aspect_ratio, uint64_t 
     else if (name == "random_spheres") setup_random_spheres(seed);
     else if (name == "mesh_in_box") setup_mesh_in_box(aspect_ratio);
     else if (name == "backrooms_pool") setup_backrooms_pool();
+    else if (name == "single_sphere") setup_single_sphere();
+    else if (name == "single_square") setup_single_square();
+    else if (name == "mesh") setup_mesh();
+    else if (name == "rt_in_a_weekend") setup_rt_in_a_weekend();
+    else if (name == "debug_refraction") setup_debug_refraction();
+    else if (name == "flamingo") setup_flamingo();
+    else if (name == "raccoon") setup_raccoon();
+    else if (name == "flamingo_pond") setup_flamingo_pond();
+    else if (name == "flamingo_lake") setup_flamingo_lake();
     else { error = "unknown scene '" + name + "'"; return false; }
     return error.empty();
 }

@@ -63,6 +63,16 @@ public:
     void setup_mesh_in_box(float aspect_ratio,                        // cfg 4: triceratops in the Cornell walls
                            const std::string &off = "mesh/triceratops.off");
     void setup_backrooms_pool();                                      // Scene.h:1329-1882 (cfg 5)
+    // demo scenes outside BASELINE.json's configs, host/scene_demo.cpp
+    void setup_single_sphere();      // Scene.h:358-382
+    void setup_single_square();      // Scene.h:384-419
+    void setup_mesh();               // Scene.h:714-827
+    void setup_rt_in_a_weekend();    // Scene.h:621-712
+    void setup_debug_refraction();   // Scene.h:926-998
+    void setup_flamingo();           // Scene.h:1000-1078
+    void setup_raccoon();            // Scene.h:1080-1207
+    void setup_flamingo_pond();      // Scene.h:1209-1262
+    void setup_flamingo_lake();      // Scene.h:1264-1327
     // Runs a setup by name: "cornell_box", "cornell_mesh", "random_spheres", "mesh_in_box", "backrooms_pool".
     bool setup_by_name(const std::string &name, float aspect_ratio, uint64_t seed);
 
