@@ -260,6 +260,8 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_meshes = min(cx.S->n_meshes, 32u);  // >= 1 in this kernel
+    const GateBox box0 = gate_box_of((cmesh)cx.S->meshes);
     // the two tile slots of the wave (wave-uniform), and this lane's pixel in each
     uint32_t tj[2], pxy[2];
     uint32_t cur = 0;     // which stream is in registers
@@ -299,6 +301,17 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
         fresh(p, tj[0], in0);
     }
 
+#ifdef HRT_DS_PROF  // diagnostic build: per-wave cycle and lane-occupancy sums -> DRender::stamps (tools/variants.sh)
+    unsigned long long prof[16];
+    for (int k = 0; k < 16; ++k) prof[k] = 0ull;
+    unsigned long long prof_last = __builtin_readcyclecounter();
+#define DSP_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                      __builtin_amdgcn_sched_barrier(0); prof[k] += t_ - prof_last; prof_last = t_; } while (0)
+#define DSP_N(k, n) do { prof[k] += (unsigned long long)(n); } while (0)
+#else
+#define DSP_T(k) do { } while (0)
+#define DSP_N(k, n) do { } while (0)
+#endif
     for (;;) {
         // ---- tile turnover: a slot whose 64 pixels are finished is written out and refilled
 #pragma unroll
@@ -331,9 +344,12 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
             }
         }
         if (tj[0] == HRT_DS_NONE && tj[1] == HRT_DS_NONE) break;
+        DSP_T(0); DSP_N(8, 1);
 
         // ---- the active stream cannot run and the other one can: swap
         if (!fl_runnable(ds_flags(p)) && fl_runnable(bak_fl)) { bak_fl = ds_swap(sb, p); cur ^= 1u; }
+        DSP_T(1);
+        DSP_N(9, __popcll(__ballot(p.live && p.stage == 0u)));
 
         // ---- stage A: (re)generate, spheres + squares, mesh gates
         if (p.live && p.stage == 0u) {
@@ -349,11 +365,14 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
                 p.rad = mk(0.f, 0.f, 0.f);
                 p.remaining = 6;  // MAXBOUNCES
             }
+            DSP_T(7);
             p.h = prims_hit(cx, p.ray);
-            p.parked = mesh_gates(cx, p.ray);
+            DSP_T(13);
+            p.parked = mesh_gates_pre(cx, p.ray, n_meshes, box0);
             p.w.ref = HRT_KD_NIL;
             p.stage = p.parked ? 1u : 2u;
         }
+        DSP_T(2);
 
         // ---- stage B: walk the meshes once enough lanes hold a parked stream
         {
@@ -369,7 +388,9 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
                     const uint64_t want = __ballot(a2 || b2);
                     if (want == 0ull || (pass == 1 && __popcll(want) < HRT_DS_SECOND)) break;
                     if (!a2 && b2) { bak_fl = ds_swap(sb, p); cur ^= 1u; }  // bring the parked stream in
+                    DSP_T(3); DSP_N(10, 1); DSP_N(11, __popcll(want));
                     if (p.live && p.stage == 1u) walk_visit(cx, p);
+                    DSP_T(4);
                 }
             } else if (aw && fl_runnable(bak_fl)) {  // not yet: trace the other stream meanwhile
                 bak_fl = ds_swap(sb, p);
@@ -377,6 +398,8 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
             }
         }
 
+        DSP_T(5);
+        DSP_N(12, __popcll(__ballot(p.live && p.stage == 2u)));
         // ---- stage C: shade, scatter, end of path
         if (p.live && p.stage == 2u) {
             bool ended;
@@ -384,7 +407,9 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
                 p.rad = p.rad + p.thr * sky(cx.S, p.ray.d, p.remaining);
                 ended = true;
             } else {
+                DSP_T(6);
                 const Surface sf = shade(cx.S, p.ray, p.h);
+                DSP_T(14);
                 f3 direct = mk(0.f, 0.f, 0.f);
                 if (LIGHTS) direct = direct_light(cx, sf, p.ray, p.rng);
                 p.rad = p.rad + p.thr * (direct + sf.emission);
@@ -401,7 +426,12 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
             }
             p.stage = 0u;
         }
+        DSP_T(6);
     }
+#ifdef HRT_DS_PROF
+    if (lane == 0 && R.stamps)
+        for (int k = 0; k < 15; ++k) atomicAdd(R.stamps + k, prof[k]);
+#endif
 }
 
 }  // namespace hrtk

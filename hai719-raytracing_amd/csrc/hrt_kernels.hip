@@ -200,16 +200,36 @@ __device__ __forceinline__ bool quad_t(Q q, const Ray &ray, float tmax, float &t
     return true;
 }
 
+// The gate box of a mesh (Mesh::computeAABB), either read from the mesh record at the point of use
+// (scalar loads) or held in registers by the caller so that no load sits on the critical path.
+struct MeshBox {
+    cmesh M;
+    __device__ __forceinline__ float lo(int a) const { return M->aabb_lo[a]; }
+    __device__ __forceinline__ float hi(int a) const { return M->aabb_hi[a]; }
+};
+struct GateBox {
+    float l[3], h[3];
+    __device__ __forceinline__ float lo(int a) const { return l[a]; }
+    __device__ __forceinline__ float hi(int a) const { return h[a]; }
+};
+__device__ __forceinline__ GateBox gate_box_of(cmesh M) {
+    GateBox b;
+    b.l[0] = M->aabb_lo[0]; b.l[1] = M->aabb_lo[1]; b.l[2] = M->aabb_lo[2];
+    b.h[0] = M->aabb_hi[0]; b.h[1] = M->aabb_hi[1]; b.h[2] = M->aabb_hi[2];
+    return b;
+}
+
 // AABB.h:48-65 exactly: reciprocal in double, products narrowed to float.
-__device__ __forceinline__ bool aabb_gate_exact(cmesh M, const Ray &ray) {
+template <class B>
+__device__ __forceinline__ bool aabb_gate_exact(const B &box, const Ray &ray) {
     float tmin = HRT_EPS, tmax = HRT_FLT_MAX;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float da = a == 0 ? ray.d.x : (a == 1 ? ray.d.y : ray.d.z);
         const float oa = a == 0 ? ray.o.x : (a == 1 ? ray.o.y : ray.o.z);
         const double adinv = 1.0 / (double)da;
-        const float t0 = (float)((double)(M->aabb_lo[a] - oa) * adinv);
-        const float t1 = (float)((double)(M->aabb_hi[a] - oa) * adinv);
+        const float t0 = (float)((double)(box.lo(a) - oa) * adinv);
+        const float t1 = (float)((double)(box.hi(a) - oa) * adinv);
         if (t0 < t1) {
             if (t0 > tmin) tmin = t0;
             if (t1 < tmax) tmax = t1;
@@ -225,13 +245,14 @@ __device__ __forceinline__ bool aabb_gate_exact(cmesh M, const Ray &ray) {
 // KDTree.cpp:82 gate.  An fp32 slab test with a margin settles the clear cases (each slab distance
 // differs from the reference's by <= 3e-7 |t|); only a ray that grazes the box within the margin, or
 // has a zero direction component, pays for the exact fp64 form.
-__device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) {
+template <class B>
+__device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 inv) {
     float g0 = HRT_EPS, g1 = HRT_FLT_MAX, big = 0.f;
-    float t0 = (M->aabb_lo[0] - ray.o.x) * inv.x, t1 = (M->aabb_hi[0] - ray.o.x) * inv.x;
+    float t0 = (box.lo(0) - ray.o.x) * inv.x, t1 = (box.hi(0) - ray.o.x) * inv.x;
     g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
-    t0 = (M->aabb_lo[1] - ray.o.y) * inv.y; t1 = (M->aabb_hi[1] - ray.o.y) * inv.y;
+    t0 = (box.lo(1) - ray.o.y) * inv.y; t1 = (box.hi(1) - ray.o.y) * inv.y;
     g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
-    t0 = (M->aabb_lo[2] - ray.o.z) * inv.z; t1 = (M->aabb_hi[2] - ray.o.z) * inv.z;
+    t0 = (box.lo(2) - ray.o.z) * inv.z; t1 = (box.hi(2) - ray.o.z) * inv.z;
     g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
     const float mg = fmaxf(fabsf(g0), fabsf(g1)) * 2e-6f + 1e-30f;
     const bool finite = big < 1e30f;  // a zero direction component makes a slab distance infinite
@@ -240,9 +261,10 @@ __device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) {
 #ifdef HRT_ABL_NO_EXACT_GATE  // ablation only: timing experiment, not parity-safe
     return true;
 #else
-    return aabb_gate_exact(M, ray);
+    return aabb_gate_exact(box, ray);
 #endif
 }
+__device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) { return mesh_gate_box(MeshBox{M}, ray, inv); }
 
 // Nodelet fetch: the leading `lds_n` units of the kd array are resident in LDS.
 __device__ __forceinline__ uint4 kd_fetch(gu4 g, const Ctx &cx, uint32_t i) {
@@ -428,6 +450,21 @@ __device__ __forceinline__ uint32_t mesh_gates(const Ctx &cx, const Ray &ray) {
     const f3 inv = ray_inv(ray);
     uint32_t m = 0;
     for (uint32_t i = 0; i < nm; ++i)
+        if (mesh_gate((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
+    return m;
+}
+
+// mesh_gates with the count and the first mesh's box already in registers (loaded once per wave): for the
+// common one-mesh scene no scalar load -- three dependent ones otherwise -- sits between the primitives and
+// the vote of every bounce.
+__device__ __forceinline__ uint32_t mesh_gates_pre(const Ctx &cx, const Ray &ray, uint32_t nm, const GateBox &box0) {
+    if (nm == 0) return 0u;
+#ifdef HRT_ABL_NO_GATES  // ablation only
+    return 0u;
+#endif
+    const f3 inv = ray_inv(ray);
+    uint32_t m = mesh_gate_box(box0, ray, inv) ? 1u : 0u;
+    for (uint32_t i = 1; i < nm; ++i)
         if (mesh_gate((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
     return m;
 }
