@@ -27,6 +27,7 @@ FLAG_NO_LDS_TREE = 2
 FLAG_WAVE_KERNEL = 4
 FLAG_STREAM_KERNEL = 8
 FLAG_NO_SHADOW_CULL = 16
+FLAG_DUAL_KERNEL = 32
 
 MAT_DIFFUSE, MAT_GLASS, MAT_MIRROR = 0, 1, 2
 TEX_NONE, TEX_CHECKER, TEX_IMAGE = 0, 1, 2

@@ -35,7 +35,7 @@ struct Runtime {
     int blocks_per_cu = 0;
     uint32_t lds_budget = 0;  // bytes of dynamic LDS per workgroup for nodelets
     bool use_dual = true;     // two pixel streams per lane (hrt_dual.hip) for scenes with meshes; HRT_KERNEL=single turns it off
-    bool use_stream = false;  // workgroup-streaming kernel (hrt_stream.hip), opt-in with HRT_KERNEL=stream
+    int use_stream = -1;      // workgroup-streaming kernel (hrt_stream.hip): -1 where it pays (default), 1 always (HRT_KERNEL=stream), 0 never
     hipFuncAttributes attr{};
 } g_rt;
 
@@ -94,6 +94,8 @@ struct hrt_scene {
     unsigned long long *stamps = nullptr;  // diagnostic cycle counters (HRT_STAMPS builds)
     float *sp_scratch = nullptr;           // per-workgroup sample scratch of the streaming kernel
     size_t sp_scratch_cap = 0;
+    uint32_t *sp_pool = nullptr;           // path records of the streaming kernel when they live in global memory
+    size_t sp_pool_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     float bound = 0.f;  // largest distance of any scene point from the origin (filter margins)
@@ -150,8 +152,9 @@ int hrt_init(int device_ordinal) {
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const char *k = std::getenv("HRT_KERNEL");
-        g_rt.use_dual = !(k && std::string(k) == "single");
-        g_rt.use_stream = (k && std::string(k) == "stream");  // opt-in until it beats the lane-per-pixel kernel
+        const std::string ks = k ? k : "";
+        g_rt.use_dual = ks != "single";
+        g_rt.use_stream = ks == "stream" ? 1 : ((ks == "single" || ks == "dual") ? 0 : -1);
     }
     g_rt.ready = true;
     return HRT_OK;
@@ -165,6 +168,7 @@ void hrt_scene_destroy(hrt_scene *s) {
     if (s->tile_counter) (void)hipFree(s->tile_counter);
     if (s->stamps) (void)hipFree(s->stamps);
     if (s->sp_scratch) (void)hipFree(s->sp_scratch);
+    if (s->sp_pool) (void)hipFree(s->sp_pool);
     if (s->d_scene) (void)hipFree(s->d_scene);
     if (s->d_cam) (void)hipFree(s->d_cam);
     if (s->d_tiles) (void)hipFree(s->d_tiles);
@@ -533,18 +537,30 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     if (accumulate) flags &= ~(uint32_t)(HRT_FLAG_GAMMA | HRT_FLAG_STREAM_KERNEL);  // hrt_finalize_tiles applies the gamma
     hipStream_t stream = (hipStream_t)stream_;
     if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
-    const bool stream_kernel = !accumulate && (g_rt.use_stream || (flags & HRT_FLAG_STREAM_KERNEL)) && !(flags & HRT_FLAG_WAVE_KERNEL);
-    const bool dual_kernel = !stream_kernel && g_rt.use_dual && s->d.n_meshes > 0u && s->max_leaf < 0xFFFFu && !(flags & HRT_FLAG_WAVE_KERNEL);
+    // Which schedule of the same arithmetic (all give identical pixels).  Measured on MI355X at 1080p: the
+    // workgroup-streaming kernel wins where bounces diverge -- meshes (+3..10 %) and lit open scenes (random_spheres
+    // +30 %) -- and loses on a closed box of squares (-45 %), where the lane-per-pixel kernel keeps its lanes busy anyway.
+    const bool stream_pays = s->d.n_meshes > 0u || s->d.n_lights > 0u;
+    const bool stream_kernel = !accumulate && !(flags & (HRT_FLAG_WAVE_KERNEL | HRT_FLAG_DUAL_KERNEL)) &&
+                               (g_rt.use_stream == 1 || (flags & HRT_FLAG_STREAM_KERNEL) || (g_rt.use_stream < 0 && stream_pays));
+    const bool dual_kernel = !stream_kernel && (g_rt.use_dual || (flags & HRT_FLAG_DUAL_KERNEL)) && s->d.n_meshes > 0u && s->max_leaf < 0xFFFFu &&
+                             !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
-        const uint32_t fixed = (uint32_t)(SP_FIELDS * HRT_SP_POOL * 4 + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + 256 * 4);
+        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4);
         uint32_t per_cu = 1024u / HRT_SP_WG;  // workgroups resident per CU (4 waves per SIMD in all) ...
         while (per_cu > 1u && 160u * 1024u / per_cu < fixed + 16u * 1024u) --per_cu;  // ... as far as the LDS pools allow
         const uint32_t room = (160u * 1024u / per_cu - fixed) / 16u;
         if (!(flags & HRT_FLAG_NO_LDS_TREE)) R.lds_units = std::min<uint32_t>(s->d.n_kd_units, room);
         lds_bytes = fixed + R.lds_units * 16u;
         grid = std::min<uint32_t>((uint32_t)g_rt.cus * per_cu, R.tiles_owned);
-        const size_t need_floats = (size_t)grid * 64u * HRT_SP_SCHUNK * 3u;
+        {   // tiles per work unit: as many as keep one unit (tiles x 64 pixels x samples per fold) within HRT_SP_UNIT paths
+            const uint32_t per_tile = 64u * std::min<uint32_t>(spp, HRT_SP_SCHUNK);
+            uint32_t glog = 0;
+            while ((2u << glog) <= HRT_SP_MAXG && (per_tile << (glog + 1u)) <= HRT_SP_UNIT) ++glog;
+            R.sp_group_log2 = glog;
+        }
+        const size_t need_floats = (size_t)grid * HRT_SP_UNIT * 3u;
         if (s->sp_scratch_cap < need_floats) {
             if (s->sp_scratch) (void)hipFree(s->sp_scratch);
             s->sp_scratch = nullptr; s->sp_scratch_cap = 0;
@@ -552,6 +568,16 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
             s->sp_scratch_cap = need_floats;
         }
         R.sp_scratch = s->sp_scratch;
+        if (HRT_SP_GLOBAL) {
+            const size_t need_words = (size_t)grid * SP_FIELDS * HRT_SP_POOL;
+            if (s->sp_pool_cap < need_words) {
+                if (s->sp_pool) (void)hipFree(s->sp_pool);
+                s->sp_pool = nullptr; s->sp_pool_cap = 0;
+                HIP_TRY(hipMalloc((void **)&s->sp_pool, need_words * sizeof(uint32_t)));
+                s->sp_pool_cap = need_words;
+            }
+        }
+        R.sp_pool = s->sp_pool;
     } else {
         const void *kfn = s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel;
         lds_bytes = R.lds_units * 16u;
@@ -572,6 +598,7 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
         const uint32_t need = (R.tiles_owned + per_wg - 1u) / per_wg;
         if (grid > need) grid = need;
         R.sp_scratch = nullptr;
+        R.sp_pool = nullptr;
     }
     s->last_grid = grid;
     s->last_lds = lds_bytes;

@@ -98,4 +98,6 @@ struct DRender {
     uint32_t *tile_counter;    // work queue head, zeroed before every launch
     unsigned long long *stamps;  // 16 cycle counters, written only by -DHRT_STAMPS diagnostic builds
     float *sp_scratch;           // streaming kernel: per-workgroup [sample][pixel][rgb] scratch of one sample chunk
+    uint32_t sp_group_log2;      // streaming kernel: log2 of the tiles per work unit
+    uint32_t *sp_pool;           // streaming kernel built with HRT_SP_GLOBAL: per-workgroup path records
 };

@@ -29,38 +29,49 @@
 #include "hrt_device.h"
 
 #ifndef HRT_SP_POOL
-#define HRT_SP_POOL 1024   // paths resident per workgroup
+#define HRT_SP_POOL 8192   // paths resident per workgroup (A/B on MI355X, 1080p@256 Cornell+mesh / mesh_in_box ms: 2048 -> 379 / 692, 4096 -> 305 / 488, 8192 -> 311 / 393)
 #endif
 #ifndef HRT_SP_WG
 #define HRT_SP_WG 1024     // threads per workgroup (16 waves = 4 per SIMD, one workgroup per CU)
 #endif
-#define HRT_SP_SCHUNK 256  // samples per pixel traced between two ordered folds
-#define HRT_SP_NQ 6        // queues: T0 T1 S0 S1 F0 F1
+#define HRT_SP_SCHUNK 1024 // most samples per pixel traced between two ordered folds
+#ifndef HRT_SP_UNIT
+#define HRT_SP_UNIT 16384  // paths of one work unit = tiles of the group x 64 pixels x samples per fold (scratch: 12 B each)
+#endif
+#define HRT_SP_MAXG 16     // most tiles per unit; a power of two
+#define HRT_SP_NQ 8        // queues: T0 T1 A0 A1 B0 B1 F0 F1 (A: sphere hits from the front, quad hits from the back;
+                           // B: misses from the front, mesh hits from the back -- a path sits in exactly one place)
 
 namespace hrtk {
 
 enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_TM, SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB,
        SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM, SP_FIELDS };
 
-struct SpCtl {           // control block in LDS (16 dwords)
-    uint32_t cT[2], cS[2], cF[2];  // queue fills, [parity]
-    uint32_t cursor;     // chunk cursor of the running cycle
+struct SpCtl {           // control block in LDS (20 dwords)
+    uint32_t cT[2], cF[2];   // queue fills, [parity]
+    uint32_t cK[4][2];       // closest-hit queues by hit kind (0 miss, 1 sphere, 2 square, 3 mesh), [kind][parity]
+    uint32_t cursor;         // chunk cursor of the running cycle
     uint32_t ngen, gen_n0, paths_left;
     uint32_t done, tile, parity, cycles;
-    uint32_t pad[2];
 };
 
 struct SpLds {
     uint32_t *st;        // SP_FIELDS x POOL dwords
     uint16_t *q;         // HRT_SP_NQ queues x POOL
     SpCtl *ctl;
-    float *run;          // 64 x 3 running pixel sums of the tile
+    float *run;          // HRT_SP_MAXG x 64 x 3 running pixel sums of the unit's tiles, then HRT_SP_MAXG packed tile origins
 };
 
-__device__ __forceinline__ float &spf(const SpLds &L, int field, uint32_t slot) {
-    return reinterpret_cast<float *>(L.st)[field * HRT_SP_POOL + slot];
-}
-__device__ __forceinline__ uint32_t &spu(const SpLds &L, int field, uint32_t slot) { return L.st[field * HRT_SP_POOL + slot]; }
+#ifndef HRT_SP_GLOBAL
+#define HRT_SP_GLOBAL 1    // 1: the path pool lives in global memory (one 96-byte record per path, L2 / Infinity Cache
+#endif                     //    resident), which lets HRT_SP_POOL grow past what LDS holds; 0: SoA arrays in LDS
+#if HRT_SP_GLOBAL
+#define SP_AT(field, slot) ((slot) * (uint32_t)SP_FIELDS + (uint32_t)(field))
+#else
+#define SP_AT(field, slot) ((uint32_t)(field) * (uint32_t)HRT_SP_POOL + (slot))
+#endif
+__device__ __forceinline__ float &spf(const SpLds &L, int field, uint32_t slot) { return reinterpret_cast<float *>(L.st)[SP_AT(field, slot)]; }
+__device__ __forceinline__ uint32_t &spu(const SpLds &L, int field, uint32_t slot) { return L.st[SP_AT(field, slot)]; }
 __device__ __forceinline__ uint16_t *spq(const SpLds &L, int which, uint32_t parity) { return L.q + (2 * which + parity) * HRT_SP_POOL; }
 
 // Wave-aggregated append of `slot` for the lanes with `want`: __ballot + one LDS atomic by the leader.
@@ -73,6 +84,26 @@ __device__ __forceinline__ void sp_push(uint16_t *q, uint32_t *count, bool want,
     if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
     base = __shfl(base, (int)leader);
     if (want) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+}
+
+// Append to the closest-hit queue of the path's hit kind: chunks of the next cycle are then homogeneous in kind, so a
+// chunk runs ONE of shade()'s branches (and mostly one of scatter()'s) instead of all of them.
+__device__ __forceinline__ void sp_push_hit(const SpLds &L, SpCtl &C, uint32_t out, bool want, uint32_t kind, uint32_t slot) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint64_t m = __ballot(want && kind == k);
+        if (m == 0ull) continue;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&C.cK[k][out], (uint32_t)__popcll(m));
+        base = __shfl(base, (int)leader);
+        if (want && kind == k) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint16_t *q = spq(L, (k == 1u || k == 2u) ? 1 : 2, out);
+            q[(k == 1u || k == 0u) ? pos : (uint32_t)HRT_SP_POOL - 1u - pos] = (uint16_t)slot;
+        }
+    }
 }
 
 __device__ __forceinline__ Ray sp_load_ray(const SpLds &L, uint32_t slot) {
@@ -103,11 +134,17 @@ template <bool LIGHTS>
 __device__ __forceinline__ void stream_body(const DRender &R) {
     extern __shared__ uint4 s_raw[];
     SpLds L;
+#if HRT_SP_GLOBAL
+    L.st = R.sp_pool + (size_t)blockIdx.x * ((size_t)SP_FIELDS * HRT_SP_POOL);
+    L.q = reinterpret_cast<uint16_t *>(s_raw);
+#else
     L.st = reinterpret_cast<uint32_t *>(s_raw);
     L.q = reinterpret_cast<uint16_t *>(L.st + SP_FIELDS * HRT_SP_POOL);
+#endif
     L.ctl = reinterpret_cast<SpCtl *>(L.q + HRT_SP_NQ * HRT_SP_POOL);
     L.run = reinterpret_cast<float *>(L.ctl + 1);
-    uint4 *s_units = reinterpret_cast<uint4 *>(L.run + 256);  // 16-byte aligned: every size above is a multiple of 16
+    uint32_t *tile_xy = reinterpret_cast<uint32_t *>(L.run + HRT_SP_MAXG * 192);  // x0 | y0 << 16 per tile of the unit, ~0: no tile
+    uint4 *s_units = reinterpret_cast<uint4 *>(tile_xy + HRT_SP_MAXG);  // 16-byte aligned: every size above is a multiple of 16
     Ctx cx;
     cx.S = (cscene)R.scene;
     cx.lds = (lu4)s_units;
@@ -124,13 +161,15 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     }
     SpCtl &C = *L.ctl;
     if (tid == 0) {
-        C.cT[0] = C.cT[1] = C.cS[0] = C.cS[1] = 0;
+        C.cT[0] = C.cT[1] = 0;
+        for (int k = 0; k < 4; ++k) C.cK[k][0] = C.cK[k][1] = 0;
         C.cF[0] = HRT_SP_POOL; C.cF[1] = 0;
         C.parity = 0; C.cycles = 0; C.done = 0;
     }
-    for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 2, 0)[i] = (uint16_t)i;  // every slot free
+    for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 3, 0)[i] = (uint16_t)i;  // every slot free
     const bool has_mesh = cx.S->n_meshes != 0u;
-    float *scratch = R.sp_scratch + (size_t)blockIdx.x * (64u * HRT_SP_SCHUNK * 3u);
+    float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNIT * 3u);
+    const uint32_t glog = R.sp_group_log2, G = 1u << glog, upix = 64u << glog;  // tiles and pixels per unit
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 #ifdef HRT_SP_DEBUG
@@ -139,18 +178,25 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #endif
     for (;;) {  // tiles
         __syncthreads();
-        if (tid == 0) C.tile = atomicAdd(R.tile_counter, 1u);
+        if (tid == 0) C.tile = atomicAdd(R.tile_counter, G);
         __syncthreads();
-        const uint32_t j = SP_UNI(C.tile);
+        const uint32_t j = SP_UNI(C.tile);  // first tile slot of the unit
         if (j >= R.tiles_owned) break;  // finite queue: every workgroup gets here
-        const uint32_t tile = R.rank + j * R.world;
-        const uint32_t tx0 = (tile % R.tiles_x) * 8u, ty0 = (tile / R.tiles_x) * 8u;
-        if (tid < 192) L.run[tid] = 0.f;
+        if (tid < G) {
+            uint32_t xy = 0xFFFFFFFFu;
+            if (j + tid < R.tiles_owned) {
+                const uint32_t tile = R.rank + (j + tid) * R.world;
+                xy = ((tile % R.tiles_x) * 8u) | (((tile / R.tiles_x) * 8u) << 16);
+            }
+            tile_xy[tid] = xy;
+        }
+        for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) L.run[i] = 0.f;
 
-        for (uint32_t s0 = 0; s0 < R.spp; s0 += HRT_SP_SCHUNK) {  // sample chunks of the tile
-            const uint32_t ns = min((uint32_t)HRT_SP_SCHUNK, R.spp - s0);
+        const uint32_t per_fold = min((uint32_t)HRT_SP_SCHUNK, (uint32_t)HRT_SP_UNIT / upix);  // samples per pixel between folds
+        for (uint32_t s0 = 0; s0 < R.spp; s0 += per_fold) {  // sample chunks of the unit
+            const uint32_t ns = min(per_fold, R.spp - s0);
             __syncthreads();
-            if (tid == 0) { C.paths_left = 64u * ns; C.gen_n0 = 0; C.cycles = 0; }
+            if (tid == 0) { C.paths_left = upix * ns; C.gen_n0 = 0; C.cycles = 0; }
             for (;;) {  // cycles
                 __syncthreads();
 #ifdef HRT_SP_DEBUG
@@ -161,9 +207,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     const uint32_t ngen = min(C.cF[par], C.paths_left);
                     C.ngen = ngen;
                     C.cursor = 0;
-                    C.cT[par ^ 1u] = 0; C.cS[par ^ 1u] = 0;
+                    C.cT[par ^ 1u] = 0;
+                    uint32_t waiting = C.cT[par];
+                    for (int k = 0; k < 4; ++k) { C.cK[k][par ^ 1u] = 0; waiting += C.cK[k][par]; }
                     C.cF[par ^ 1u] = C.cF[par] - ngen;  // the unused free slots carry over, S appends after them
-                    C.done = (ngen == 0u && C.cT[par] == 0u && C.cS[par] == 0u) ? 1u : 0u;
+                    C.done = (ngen == 0u && waiting == 0u) ? 1u : 0u;
                     if (++C.cycles > (1u << 16)) {  // bounded: a scheduling bug must not spin the GPU; the host reports it
                         if (R.stamps) R.stamps[15] = 0xDEADull;
                         C.done = 1u;
@@ -173,12 +221,16 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 if (SP_UNI(C.done)) break;
                 const uint32_t parity = SP_UNI(C.parity);
                 const uint32_t ngen = SP_UNI(C.ngen), cFin = SP_UNI(C.cF[parity]), n0 = SP_UNI(C.gen_n0);
-                const uint32_t cTin = SP_UNI(C.cT[parity]), cSin = SP_UNI(C.cS[parity]);
-                const uint32_t nT = (cTin + 63u) >> 6, nS = (cSin + 63u) >> 6, nG = (ngen + 63u) >> 6, total = nT + nS + nG;
+                const uint32_t cTin = SP_UNI(C.cT[parity]);
+                const uint32_t cK0 = SP_UNI(C.cK[0][parity]), cK1 = SP_UNI(C.cK[1][parity]), cK2 = SP_UNI(C.cK[2][parity]),
+                               cK3 = SP_UNI(C.cK[3][parity]);
+                // chunk ranges of this cycle: T (longest) first, then mesh, sphere, square hits, misses, new paths last
+                const uint32_t nT = (cTin + 63u) >> 6, e3 = nT + ((cK3 + 63u) >> 6), e1 = e3 + ((cK1 + 63u) >> 6),
+                               e2 = e1 + ((cK2 + 63u) >> 6), e0 = e2 + ((cK0 + 63u) >> 6), nG = (ngen + 63u) >> 6, total = e0 + nG;
                 uint16_t *qTi = spq(L, 0, parity), *qTo = spq(L, 0, parity ^ 1u);
-                uint16_t *qSi = spq(L, 1, parity), *qSo = spq(L, 1, parity ^ 1u);
-                uint16_t *qFi = spq(L, 2, parity), *qFo = spq(L, 2, parity ^ 1u);
-                uint32_t *cTo = &C.cT[parity ^ 1u], *cSo = &C.cS[parity ^ 1u], *cFo = &C.cF[parity ^ 1u];
+                uint16_t *qAi = spq(L, 1, parity), *qBi = spq(L, 2, parity);
+                uint16_t *qFi = spq(L, 3, parity), *qFo = spq(L, 3, parity ^ 1u);
+                uint32_t *cTo = &C.cT[parity ^ 1u], *cFo = &C.cF[parity ^ 1u];
                 for (uint32_t i = tid; i < cFin - ngen; i += HRT_SP_WG) qFo[i] = qFi[ngen + i];  // carry unused free slots
 #ifdef HRT_SP_DEBUG
                 const unsigned long long dbg_w0 = __builtin_readcyclecounter();
@@ -197,30 +249,37 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         // ---------------- T: mesh walk
                         const uint32_t e = c * 64u + lane;
                         const bool act = e < cTin;
-                        uint32_t slot = 0;
+                        uint32_t slot = 0, kind = 0;
                         if (act) {
                             slot = qTi[e] & (HRT_SP_POOL - 1u);
                             const Ray ray = sp_load_ray(L, slot);
                             Hit h = sp_load_hit(L, slot);
                             meshes_hit(cx, ray, spu(L, SP_PM, slot), h);
                             sp_store_hit(L, slot, h, 0u);
+                            kind = h.kind;
                         }
-                        sp_push(qSo, cSo, act, slot);
+                        sp_push_hit(L, C, parity ^ 1u, act, kind, slot);
                     } else {
                         // ---------------- S (shade + scatter, then next prims) and G (camera ray, then prims)
-                        const bool is_gen = c >= nT + nS;
-                        const uint32_t e = (is_gen ? c - nT - nS : c - nT) * 64u + lane;
-                        const bool act = e < (is_gen ? ngen : cSin);
-                        uint32_t slot = 0;
+                        const bool is_gen = c >= e0;
+                        // which closest-hit queue this chunk drains: its entries, its fill, and where entry e sits
+                        const uint32_t first = is_gen ? e0 : (c < e3 ? nT : (c < e1 ? e3 : (c < e2 ? e1 : e2)));
+                        const uint32_t fill = is_gen ? ngen : (c < e3 ? cK3 : (c < e1 ? cK1 : (c < e2 ? cK2 : cK0)));
+                        const bool from_back = !is_gen && (c < e3 || (c >= e1 && c < e2));  // mesh and square hits grow from the end
+                        const uint16_t *qHi = (c < e3 || c >= e2) ? qBi : qAi;
+                        const uint32_t e = (c - first) * 64u + lane;
+                        const bool act = e < fill;
+                        uint32_t slot = 0, kind = 0;
                         bool trace = false, freed = false;  // trace: the path has a new ray to intersect
                         Ray ray;
                         ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
                         if (act && is_gen) {
                             slot = qFi[e] & (HRT_SP_POOL - 1u);
-                            const uint32_t n = n0 + e;  // path n of the chunk = (sample n / 64, pixel n % 64)
-                            const uint32_t p = n & 63u, s = s0 + (n >> 6);
-                            const uint32_t px = tx0 + (p & 7u), py = ty0 + (p >> 3);
-                            if (px < R.w && py < R.h) {
+                            const uint32_t n = n0 + e;  // path n of the unit = (sample n / upix, pixel n % upix)
+                            const uint32_t q = n & (upix - 1u), s = s0 + (n >> (6u + glog));
+                            const uint32_t p = q & 63u, txy = tile_xy[q >> 6];
+                            const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
+                            if (txy != 0xFFFFFFFFu && px < R.w && py < R.h) {
                                 Rng rng;
                                 rng.start(R.seed_lo, R.seed_hi, py * R.w + px, s);
                                 const float u = ((float)px + rng.next()) / (float)R.w;
@@ -239,7 +298,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 freed = true;
                             }
                         } else if (act) {
-                            slot = qSi[e] & (HRT_SP_POOL - 1u);
+                            slot = qHi[from_back ? (uint32_t)HRT_SP_POOL - 1u - e : e] & (HRT_SP_POOL - 1u);
                             ray = sp_load_ray(L, slot);
                             const Hit h = sp_load_hit(L, slot);
                             f3 thr = mk(spf(L, SP_TR, slot), spf(L, SP_TG, slot), spf(L, SP_TB, slot));
@@ -269,7 +328,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 }
                             }
                             if (ended) {  // Scene.h:348: the sample's colour, parked until the ordered fold
-                                const uint32_t n = min(spu(L, SP_N, slot), 64u * HRT_SP_SCHUNK - 1u);  // stays inside the scratch
+                                const uint32_t n = min(spu(L, SP_N, slot), (uint32_t)HRT_SP_UNIT - 1u);  // stays inside the scratch
                                 float *o = scratch + (size_t)n * 3u;
                                 o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
                                 freed = true;
@@ -283,9 +342,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             sp_store_ray(L, slot, ray);
                             sp_store_hit(L, slot, h, pm);
                             to_mesh = pm != 0u;
+                            kind = h.kind;
                         }
                         sp_push(qTo, cTo, trace && to_mesh, slot);
-                        sp_push(qSo, cSo, trace && !to_mesh, slot);
+                        sp_push_hit(L, C, parity ^ 1u, trace && !to_mesh, kind, slot);
                         sp_push(qFo, cFo, freed, slot);
                     }
                 }
@@ -297,23 +357,23 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             }
             // the chunk has drained: fold its samples into the pixel sums in sample order (main.cpp:193)
             __syncthreads();
-            if (tid < 192) {
-                const uint32_t p = tid / 3u, ch = tid % 3u;
-                float acc = L.run[tid];
+            for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {  // i = pixel-of-unit * 3 + channel
+                float acc = L.run[i];
                 // agent-scope relaxed loads (global_load ... sc1): served by L2, never by a stale L1 line of an
                 // earlier chunk that other waves of this workgroup have since overwritten
                 for (uint32_t s = 0; s < ns; ++s)
-                    acc += __hip_atomic_load(scratch + ((size_t)s * 64u + p) * 3u + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                L.run[tid] = acc;
+                    acc += __hip_atomic_load(scratch + (size_t)s * (upix * 3u) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.run[i] = acc;
             }
         }
         __syncthreads();
-        if (tid < 192) {
-            const uint32_t p = tid / 3u;
-            const uint32_t px = tx0 + (p & 7u), py = ty0 + (p >> 3);
+        for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {
+            const uint32_t q = i / 3u, p = q & 63u, txy = tile_xy[q >> 6];
+            if (txy == 0xFFFFFFFFu) continue;  // no such tile: nothing to write
+            const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
             float c = 0.f;
-            if (px < R.w && py < R.h) c = L.run[tid] / (float)R.spp;  // main.cpp:195
-            R.out_tiles[(size_t)j * 192u + tid] = c;
+            if (px < R.w && py < R.h) c = L.run[i] / (float)R.spp;  // main.cpp:195
+            R.out_tiles[(size_t)j * 192u + i] = c;
         }
     }
 #ifdef HRT_SP_DEBUG

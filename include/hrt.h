@@ -159,9 +159,10 @@ typedef struct hrt_camera {
 enum {
     HRT_FLAG_GAMMA = 1u,       /* apply pow(c,1/2.2) (main.cpp:196)             */
     HRT_FLAG_NO_LDS_TREE = 2u, /* debug: fetch every nodelet from global memory */
-    HRT_FLAG_WAVE_KERNEL = 4u, /* force the one-pixel-per-lane kernel (default: two pixel streams per lane when the scene has meshes) */
-    HRT_FLAG_STREAM_KERNEL = 8u, /* force the experimental workgroup-streaming kernel; all three give identical pixels */
-    HRT_FLAG_NO_SHADOW_CULL = 16u /* debug: shadow rays test every sphere (the reference's loop) instead of the culled groups */
+    HRT_FLAG_WAVE_KERNEL = 4u, /* force the one-pixel-per-lane kernel                                             */
+    HRT_FLAG_STREAM_KERNEL = 8u, /* force the workgroup-streaming kernel (the default for scenes with meshes or lights) */
+    HRT_FLAG_NO_SHADOW_CULL = 16u, /* debug: shadow rays test every sphere (the reference's loop) instead of the culled groups */
+    HRT_FLAG_DUAL_KERNEL = 32u /* force the two-streams-per-lane kernel (mesh scenes; all kernel forms give identical pixels) */
 };
 
 typedef struct hrt_stats {
