@@ -2,8 +2,8 @@
 // gfx950 only.  No CPU fallback: every entry point that needs the GPU fails
 // with HRT_ERR_DEVICE when HIP cannot provide one.
 #include "hrt_kernels.hip"
-#include "hrt_stream.hip"
 #include "hrt_dual.hip"
+#include "hrt_stream.hip"
 #include "hrt_output.hip"
 
 #include <chrono>

@@ -222,22 +222,28 @@ __device__ __forceinline__ bool mesh_walk(const Ctx &cx, cmesh M, const Ray &ray
     return ref == HRT_KD_NIL;
 }
 
-// One stage B visit for a parked stream: HRT_DS_TRIPS trips on each mesh in turn (Scene.h:222-228 order).
-__device__ __forceinline__ void walk_visit(const Ctx &cx, PathState &p) {
-    const f3 inv = ray_inv(p.ray);
+// Up to `trips` trips on each mesh still to be walked, in mesh order (Scene.h:222-228); a finished mesh is merged
+// into the closest hit with the caller's `t >= EPSILON && t < best` and leaves `parked`.  True when none is left.
+__device__ __forceinline__ bool walk_some(const Ctx &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
+    const f3 inv = ray_inv(ray);
     const uint32_t nm = min(cx.S->n_meshes, 32u);
     for (uint32_t i = 0; i < nm; ++i) {  // wave-uniform loop: scalar mesh records
-        if ((p.parked & (0u - p.parked)) == (1u << i)) {  // mesh i is this lane's next one
-            if (mesh_walk(cx, (cmesh)cx.S->meshes + i, p.ray, inv, p.w, HRT_DS_TRIPS)) {
-                const float t = p.w.best_t;
-                if (t < HRT_FLT_MAX && t < p.h.t && HRT_T_ACCEPT(t)) {
-                    p.h.kind = 3; p.h.index = i; p.h.t = t; p.h.tri = p.w.best_tri; p.h.a0 = p.w.bu; p.h.a1 = p.w.bv;
+        if ((parked & (0u - parked)) == (1u << i)) {  // mesh i is this lane's next one
+            if (mesh_walk(cx, (cmesh)cx.S->meshes + i, ray, inv, w, trips)) {
+                const float t = w.best_t;
+                if (t < HRT_FLT_MAX && t < h.t && HRT_T_ACCEPT(t)) {
+                    h.kind = 3; h.index = i; h.t = t; h.tri = w.best_tri; h.a0 = w.bu; h.a1 = w.bv;
                 }
-                p.parked &= ~(1u << i);
+                parked &= ~(1u << i);
             }
         }
     }
-    if (p.parked == 0u) p.stage = 2u;
+    return parked == 0u;
+}
+
+// One stage B visit for a parked stream.
+__device__ __forceinline__ void walk_visit(const Ctx &cx, PathState &p) {
+    if (walk_some(cx, p.ray, p.parked, p.w, p.h, HRT_DS_TRIPS)) p.stage = 2u;
 }
 
 template <bool LIGHTS>

@@ -29,23 +29,29 @@
 #include "hrt_device.h"
 
 #ifndef HRT_SP_POOL
-#define HRT_SP_POOL 8192   // paths resident per workgroup (A/B on MI355X, 1080p@256 Cornell+mesh / mesh_in_box ms: 2048 -> 379 / 692, 4096 -> 305 / 488, 8192 -> 311 / 393)
+#define HRT_SP_POOL 4096   // paths resident per workgroup, 128-byte records.  A/B on MI355X, 1080p@256, ms Cornell+mesh / mesh_in_box / pool:
+                           // 2048 -> 306 / 354 / 775, 4096 -> 278 / 320 / 673 (unit 32768), 8192 -> 360 / 391 / 730: pool + scratch of all
+                           // 256 workgroups should stay within the 256 MB Infinity Cache
 #endif
 #ifndef HRT_SP_WG
 #define HRT_SP_WG 1024     // threads per workgroup (16 waves = 4 per SIMD, one workgroup per CU)
 #endif
 #define HRT_SP_SCHUNK 1024 // most samples per pixel traced between two ordered folds
 #ifndef HRT_SP_UNIT
-#define HRT_SP_UNIT 16384  // paths of one work unit = tiles of the group x 64 pixels x samples per fold (scratch: 12 B each)
+#define HRT_SP_UNIT 32768  // paths of one work unit = tiles of the group x 64 pixels x samples per fold (scratch: 12 B each)
 #endif
 #define HRT_SP_MAXG 16     // most tiles per unit; a power of two
+#ifndef HRT_SP_TRIPS
+#define HRT_SP_TRIPS 8     // KD-walk trips per T visit; an unfinished walk goes back to the T queue with its state
+#endif
 #define HRT_SP_NQ 8        // queues: T0 T1 A0 A1 B0 B1 F0 F1 (A: sphere hits from the front, quad hits from the back;
                            // B: misses from the front, mesh hits from the back -- a path sits in exactly one place)
 
 namespace hrtk {
 
 enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_TM, SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB,
-       SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM, SP_FIELDS };
+       SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM,
+       SP_WREF, SP_WTE, SP_WKK, SP_WBT, SP_WTRI, SP_WBU, SP_WBV, SP_PAD, SP_FIELDS };  // 32 dwords: one 128-byte record
 
 struct SpCtl {           // control block in LDS (20 dwords)
     uint32_t cT[2], cF[2];   // queue fills, [parity]
@@ -250,15 +256,25 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         const uint32_t e = c * 64u + lane;
                         const bool act = e < cTin;
                         uint32_t slot = 0, kind = 0;
+                        bool walked = false;
                         if (act) {
                             slot = qTi[e] & (HRT_SP_POOL - 1u);
                             const Ray ray = sp_load_ray(L, slot);
                             Hit h = sp_load_hit(L, slot);
-                            meshes_hit(cx, ray, spu(L, SP_PM, slot), h);
-                            sp_store_hit(L, slot, h, 0u);
+                            uint32_t pm = spu(L, SP_PM, slot);
+                            Walk w;
+                            w.ref = spu(L, SP_WREF, slot); w.t_entry = spf(L, SP_WTE, slot); w.kk = spu(L, SP_WKK, slot);
+                            w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
+                            w.bv = spf(L, SP_WBV, slot);
+                            walked = walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
+                            sp_store_hit(L, slot, h, pm);
+                            spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
+                            spf(L, SP_WBT, slot) = w.best_t; spu(L, SP_WTRI, slot) = w.best_tri; spf(L, SP_WBU, slot) = w.bu;
+                            spf(L, SP_WBV, slot) = w.bv;
                             kind = h.kind;
                         }
-                        sp_push_hit(L, C, parity ^ 1u, act, kind, slot);
+                        sp_push(qTo, cTo, act && !walked, slot);  // unfinished: joins the next cycle's T chunks
+                        sp_push_hit(L, C, parity ^ 1u, act && walked, kind, slot);
                     } else {
                         // ---------------- S (shade + scatter, then next prims) and G (camera ray, then prims)
                         const bool is_gen = c >= e0;
@@ -341,6 +357,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             const uint32_t pm = has_mesh ? mesh_gates(cx, ray) : 0u;
                             sp_store_ray(L, slot, ray);
                             sp_store_hit(L, slot, h, pm);
+                            spu(L, SP_WREF, slot) = HRT_KD_NIL;  // no walk in progress
                             to_mesh = pm != 0u;
                             kind = h.kind;
                         }
