@@ -49,9 +49,11 @@
 
 namespace hrtk {
 
-enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_TM, SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB,
-       SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM,
-       SP_WREF, SP_WTE, SP_WKK, SP_WBT, SP_WTRI, SP_WBU, SP_WBV, SP_PAD, SP_FIELDS };  // 32 dwords: one 128-byte record
+// One path = one 128-byte record.  Dwords 0-19 are what a T visit touches (ray, best hit, meshes to walk, walk
+// state: five aligned 16-byte groups), 0-11 and 20-31 what a hit / new-path visit touches.
+enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM,
+       SP_WREF, SP_WTE, SP_WKK, SP_WBT, SP_WTRI, SP_WBU, SP_WBV, SP_PAD,
+       SP_TM, SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB, SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_FIELDS };  // 32 dwords: one 128-byte record
 
 struct SpCtl {           // control block in LDS (20 dwords)
     uint32_t cT[2], cF[2];   // queue fills, [parity]
@@ -266,11 +268,14 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             w.ref = spu(L, SP_WREF, slot); w.t_entry = spf(L, SP_WTE, slot); w.kk = spu(L, SP_WKK, slot);
                             w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
                             w.bv = spf(L, SP_WBV, slot);
+                            const uint32_t pm_in = pm;
                             walked = walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
-                            sp_store_hit(L, slot, h, pm);
-                            spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
-                            spf(L, SP_WBT, slot) = w.best_t; spu(L, SP_WTRI, slot) = w.best_tri; spf(L, SP_WBU, slot) = w.bu;
-                            spf(L, SP_WBV, slot) = w.bv;
+                            if (pm != pm_in) sp_store_hit(L, slot, h, pm);  // a mesh was finished: the best hit may have changed
+                            if (!walked) {  // the state of the walk in progress (the next bounce starts from SP_WREF = NIL)
+                                spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
+                                spf(L, SP_WBT, slot) = w.best_t; spu(L, SP_WTRI, slot) = w.best_tri; spf(L, SP_WBU, slot) = w.bu;
+                                spf(L, SP_WBV, slot) = w.bv;
+                            }
                             kind = h.kind;
                         }
                         sp_push(qTo, cTo, act && !walked, slot);  // unfinished: joins the next cycle's T chunks
