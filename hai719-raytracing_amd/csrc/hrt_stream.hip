@@ -42,7 +42,8 @@
 #endif
 #define HRT_SP_MAXG 16     // most tiles per unit; a power of two
 #ifndef HRT_SP_TRIPS
-#define HRT_SP_TRIPS 8     // KD-walk trips per T visit; an unfinished walk goes back to the T queue with its state
+#define HRT_SP_TRIPS 6     // KD-walk trips per T visit (A/B 1080p@256, ms Cornell+mesh / mesh_in_box / pool: 6 -> 264 / 301 / 649, 8 -> 264 / 305 / 659, 12 -> 265 / 311 / 686);
+                           // an unfinished walk goes back to the T queue with its state
 #endif
 #define HRT_SP_NQ 8        // queues: T0 T1 A0 A1 B0 B1 F0 F1 (A: sphere hits from the front, quad hits from the back;
                            // B: misses from the front, mesh hits from the back -- a path sits in exactly one place)
