@@ -1,31 +1,35 @@
-// hrt_wgstream_kernel -- the workgroup-streaming form of the trace megakernel (included by hrt_api.hip
-// after hrt_kernels.hip, whose exact-arithmetic device functions it reuses unchanged).
+// hrt_wgstream_kernel -- the workgroup-streaming form of the trace megakernel (included by hrt_api.hip after
+// hrt_kernels.hip and hrt_dual.hip, whose exact-arithmetic device functions it reuses unchanged).
 //
-// WHY.  In hrt_trace_kernel a lane owns a pixel and walks all stages of every bounce itself; the PMC
-// profile (profiles/r01_pmc.json) shows 40 % VALU lane utilisation on Cornell+mesh because on any given
-// bounce the 64 lanes of a wave want different things (new camera ray / mesh walk / shade).  Here the
-// divergent rays are COMPACTED: a workgroup keeps a pool of HRT_SP_POOL paths in LDS (SoA, 24 dwords
-// per path) and stage queues of 16-bit slot ids.  One cycle runs three kinds of 64-entry chunks:
-//     G  free slot          -> camera ray (main.cpp:188-192), spheres + squares, mesh box gates
-//     T  ray + best hit     -> rope KD walk of the gated meshes
-//     S  closest hit        -> sky | shade + direct light + scatter (path end -> free list),
-//                              then spheres + squares + gates for the scattered ray
-// G and S hand the path to T when its ray enters a mesh box, else to S.  Queues are double-buffered:
-// a cycle consumes the "in" buffers, frozen at its start, and appends to the "out" buffers, so all
-// stages run in the SAME cycle between one pair of barriers; the waves pull chunks from one LDS cursor
-// (dynamic balance inside the workgroup).  Appends are wave-aggregated: one __ballot, one LDS atomicAdd
-// by the leader lane, positions by popcount of the lower lanes (__shfl of the base).
+// WHY.  In hrt_trace_kernel a lane owns a pixel and walks all stages of every bounce itself; the PMC profile
+// (profiles/r01_pmc.json) shows 40 % VALU lane utilisation on Cornell+mesh because on any given bounce the 64
+// lanes of a wave want different things (new camera ray / mesh walk / shade a sphere, a square, a triangle).
+// Here the divergent rays are COMPACTED.  A 1024-thread workgroup (one per CU) keeps a pool of HRT_SP_POOL
+// paths as 128-byte records in global memory (sized to stay in the Infinity Cache) and queues of 16-bit slot
+// ids in LDS.  One cycle runs 64-entry chunks of
+//     G   free slot          -> camera ray (main.cpp:188-192), spheres + squares, mesh box gates
+//     T   ray + best hit     -> up to HRT_SP_TRIPS trips of the rope KD walk; an unfinished walk keeps its state
+//                               in the record and comes back next cycle, so T chunks stay full
+//     H_k closest hit, by kind k = miss / sphere / square / mesh: sky | shade + direct light + scatter (path end
+//                               -> free list), then spheres + squares + gates for the scattered ray
+// G and H hand the path to T when its ray enters a mesh box, else to the hit queue of its kind; T does the same
+// when the walk is complete.  Sorting by kind makes a chunk run ONE branch of shade().  Queues are double-
+// buffered: a cycle consumes the "in" buffers, frozen at its start, and appends to the "out" buffers, so all
+// stages run in the SAME cycle between one pair of barriers; the 16 waves pull chunks from one LDS cursor
+// (T first: the longest).  Appends are wave-aggregated: one __ballot, one LDS atomicAdd by the leader lane,
+// positions by popcount of the lower lanes (__shfl of the base).  With 4096 paths a cycle offers ~64 chunks,
+// so the waves' wait at the cycle barrier is ~8 % (it was 62 % with the 1024-path pool that fits in LDS).
 //
-// Every control value is written by thread 0 between two barriers and read back through
-// readfirstlane, so all loops around the barriers are provably wave-uniform for the compiler.  (With
-// per-thread copies of the same values hipcc if-converted the loop exits into exec masks and waves
-// left the barrier sequence at different points: wrong pixels, hangs.)
+// Every control value is written by thread 0 between two barriers and read back through readfirstlane, so all
+// loops around the barriers are provably wave-uniform for the compiler.  (With per-thread copies of the same
+// values hipcc if-converted the loop exits into exec masks and waves left the barrier sequence at different
+// points: wrong pixels, hangs.)  A cycle bound (1 << 16) ends a run that a scheduling bug would otherwise spin.
 //
-// DETERMINISM.  A path is keyed (pixel, sample) as before, so the schedule cannot change its random
-// numbers or its arithmetic.  Finished samples go to a per-workgroup scratch indexed by sample-major
-// path number and are folded into the pixel sum in sample order after the tile's sample chunk has
-// drained: the fold is the reference's `image += color` order (main.cpp:193), bit for bit, whatever
-// order paths finished in.
+// DETERMINISM.  A path is keyed (pixel, sample) as before, so the schedule cannot change its random numbers or
+// its arithmetic.  A work unit is up to 16 tiles x 64 pixels x the samples of one fold (<= HRT_SP_UNIT paths);
+// finished samples go to a per-workgroup scratch indexed by sample-major path number and are folded into the
+// pixel sums in sample order when the unit has drained: the fold is the reference's `image += color` order
+// (main.cpp:193), bit for bit, whatever order paths finished in.
 #include "hrt_device.h"
 
 #ifndef HRT_SP_POOL
@@ -33,6 +37,9 @@
                            // 2048 -> 306 / 354 / 775, 4096 -> 278 / 320 / 673 (unit 32768), 8192 -> 360 / 391 / 730: pool + scratch of all
                            // 256 workgroups should stay within the 256 MB Infinity Cache
 #endif
+#ifndef HRT_SP_GLOBAL
+#define HRT_SP_GLOBAL 1    // 1: the path pool lives in global memory (one 128-byte record per path, L2 / Infinity Cache
+#endif                     //    resident), which lets HRT_SP_POOL grow past what LDS holds; 0: SoA arrays in LDS
 #ifndef HRT_SP_WG
 #define HRT_SP_WG 1024     // threads per workgroup (16 waves = 4 per SIMD, one workgroup per CU)
 #endif
@@ -64,6 +71,10 @@ struct SpCtl {           // control block in LDS (20 dwords)
     uint32_t done, tile, parity, cycles;
 };
 
+static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
+static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_MAXG * 196 * 4 + 128 <= 160 * 1024,
+              "pool + queues do not fit the CU's 160 KB of LDS (with HRT_SP_GLOBAL=0 use -DHRT_SP_POOL=1024)");
+
 struct SpLds {
     uint32_t *st;        // SP_FIELDS x POOL dwords
     uint16_t *q;         // HRT_SP_NQ queues x POOL
@@ -71,9 +82,6 @@ struct SpLds {
     float *run;          // HRT_SP_MAXG x 64 x 3 running pixel sums of the unit's tiles, then HRT_SP_MAXG packed tile origins
 };
 
-#ifndef HRT_SP_GLOBAL
-#define HRT_SP_GLOBAL 1    // 1: the path pool lives in global memory (one 96-byte record per path, L2 / Infinity Cache
-#endif                     //    resident), which lets HRT_SP_POOL grow past what LDS holds; 0: SoA arrays in LDS
 #if HRT_SP_GLOBAL
 #define SP_AT(field, slot) ((slot) * (uint32_t)SP_FIELDS + (uint32_t)(field))
 #else
