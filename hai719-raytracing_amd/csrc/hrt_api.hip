@@ -534,14 +534,14 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     R.out_tiles = d_tiles;
     R.s0 = s0;
     R.accumulate = accumulate ? 1u : 0u;
-    if (accumulate) flags &= ~(uint32_t)(HRT_FLAG_GAMMA | HRT_FLAG_STREAM_KERNEL);  // hrt_finalize_tiles applies the gamma
+    if (accumulate) flags &= ~(uint32_t)HRT_FLAG_GAMMA;  // hrt_finalize_tiles applies the gamma
     hipStream_t stream = (hipStream_t)stream_;
     if (R.tiles_owned == 0) { s->timed = false; return HRT_OK; }
     // Which schedule of the same arithmetic (all give identical pixels).  Measured on MI355X at 1080p: the
     // workgroup-streaming kernel wins where bounces diverge -- meshes (+3..10 %) and lit open scenes (random_spheres
     // +30 %) -- and loses on a closed box of squares (-45 %), where the lane-per-pixel kernel keeps its lanes busy anyway.
     const bool stream_pays = s->d.n_meshes > 0u || s->d.n_lights > 0u;
-    const bool stream_kernel = !accumulate && !(flags & (HRT_FLAG_WAVE_KERNEL | HRT_FLAG_DUAL_KERNEL)) &&
+    const bool stream_kernel = !(flags & (HRT_FLAG_WAVE_KERNEL | HRT_FLAG_DUAL_KERNEL)) &&
                                (g_rt.use_stream == 1 || (flags & HRT_FLAG_STREAM_KERNEL) || (g_rt.use_stream < 0 && stream_pays));
     const bool dual_kernel = !stream_kernel && (g_rt.use_dual || (flags & HRT_FLAG_DUAL_KERNEL)) && s->d.n_meshes > 0u && s->max_leaf < 0xFFFFu &&
                              !(flags & HRT_FLAG_WAVE_KERNEL);

@@ -207,7 +207,12 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             }
             tile_xy[tid] = xy;
         }
-        for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) L.run[i] = 0.f;
+        for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {
+            float start = 0.f;
+            // progressive mode: continue the running sums of samples [0, s0) (tiles beyond the last one: never read back)
+            if (R.accumulate && j + i / 192u < R.tiles_owned) start = R.out_tiles[(size_t)j * 192u + i];
+            L.run[i] = start;
+        }
 
         const uint32_t per_fold = min((uint32_t)HRT_SP_SCHUNK, (uint32_t)HRT_SP_UNIT / upix);  // samples per pixel between folds
         for (uint32_t s0 = 0; s0 < R.spp; s0 += per_fold) {  // sample chunks of the unit
@@ -311,7 +316,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
                             if (txy != 0xFFFFFFFFu && px < R.w && py < R.h) {
                                 Rng rng;
-                                rng.start(R.seed_lo, R.seed_hi, py * R.w + px, s);
+                                rng.start(R.seed_lo, R.seed_hi, py * R.w + px, R.s0 + s);
                                 const float u = ((float)px + rng.next()) / (float)R.w;
                                 const float v = ((float)py + rng.next()) / (float)R.h;
                                 const float tm = rng.next();
@@ -403,7 +408,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             if (txy == 0xFFFFFFFFu) continue;  // no such tile: nothing to write
             const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
             float c = 0.f;
-            if (px < R.w && py < R.h) c = L.run[i] / (float)R.spp;  // main.cpp:195
+            if (px < R.w && py < R.h) c = R.accumulate ? L.run[i] : L.run[i] / (float)R.spp;  // main.cpp:195; progressive mode keeps the sum
             R.out_tiles[(size_t)j * 192u + i] = c;
         }
     }

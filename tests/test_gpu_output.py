@@ -25,7 +25,7 @@ def one_shot(gpu, dev, cam, w, h, spp, seed, flags, world=1):
     return frame
 
 
-@pytest.mark.parametrize("name,flags_name,world", [("cornell_mesh", None, 1), ("cornell_mesh", "FLAG_WAVE_KERNEL", 2),
+@pytest.mark.parametrize("name,flags_name,world", [("cornell_mesh", None, 1), ("cornell_mesh", "FLAG_WAVE_KERNEL", 2), ("cornell_mesh", "FLAG_DUAL_KERNEL", 1),
                                                    ("random_spheres", None, 1), ("backrooms_pool", None, 3)])
 def test_progressive_chunks_leave_the_bits_of_the_one_shot_render(gpu, name, flags_name, world):
     """Samples added in chunks of 3 + 1 + 8 + 4 (per-pixel sums continue in sample order) == 16 spp at once,
