@@ -423,5 +423,5 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 
 }  // namespace hrtk
 
-extern "C" __global__ void __launch_bounds__(HRT_SP_WG) hrt_wgstream_kernel(const DRender R) { hrtk::stream_body<false>(R); }
-extern "C" __global__ void __launch_bounds__(HRT_SP_WG) hrt_wgstream_kernel_lights(const DRender R) { hrtk::stream_body<true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, 4) hrt_wgstream_kernel(const DRender R) { hrtk::stream_body<false>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, 4) hrt_wgstream_kernel_lights(const DRender R) { hrtk::stream_body<true>(R); }
