@@ -2,7 +2,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <deque>
 
 namespace hrt_host {
@@ -51,40 +56,82 @@ struct Builder {
         return (int)nodes.size() - 1;
     }
 
-    // Surface-area heuristic over all triangle-bound planes strictly inside the cell.
-    bool best_split(const Box &cell, const std::vector<TriRef> &refs, int &axis_out, float &pos_out) {
+    // Surface-area heuristic over all triangle-bound planes strictly inside the cell.  The three axes are
+    // independent; for big nodes (the sequential top of a threaded build) they run on three threads and are
+    // reduced in axis order with the same strict `<`, so the chosen plane is the sequential one.
+    struct AxisBest { float cost; float pos; bool found; };
+    AxisBest best_on_axis(const Box &cell, const std::vector<TriRef> &refs, int a, float leaf_cost) const {
+        AxisBest r{leaf_cost, 0.f, false};
+        if (!(cell.hi[a] > cell.lo[a])) return r;
         const size_t n = refs.size();
         const float inv_area = 1.f / std::max(cell.area(), 1e-30f);
-        float best = prm.cost_intersect * (float)n;  // cost of not splitting
-        bool found = false;
         std::vector<float> mins(n), maxs(n);
-        for (int a = 0; a < 3; ++a) {
-            if (!(cell.hi[a] > cell.lo[a])) continue;
-            for (size_t i = 0; i < n; ++i) { mins[i] = refs[i].b.lo[a]; maxs[i] = refs[i].b.hi[a]; }
-            std::sort(mins.begin(), mins.end());
-            std::sort(maxs.begin(), maxs.end());
-            auto consider = [&](float p) {
-                if (!(p > cell.lo[a]) || !(p < cell.hi[a])) return;
-                size_t nl = std::lower_bound(mins.begin(), mins.end(), p) - mins.begin();  // min < p
-                size_t nr = n - (std::upper_bound(maxs.begin(), maxs.end(), p) - maxs.begin());  // max > p
-                Box L = cell, R = cell;
-                L.hi[a] = p;
-                R.lo[a] = p;
-                float c = prm.cost_traverse +
-                          prm.cost_intersect * inv_area * (L.area() * (float)nl + R.area() * (float)nr);
-                if (nl == 0 || nr == 0) c *= prm.empty_bonus;
-                if (c < best) { best = c; axis_out = a; pos_out = p; found = true; }
-            };
-            float last = NAN;
-            for (size_t i = 0; i < n; ++i) if (mins[i] != last) { last = mins[i]; consider(last); }
-            last = NAN;
-            for (size_t i = 0; i < n; ++i) if (maxs[i] != last) { last = maxs[i]; consider(last); }
+        for (size_t i = 0; i < n; ++i) { mins[i] = refs[i].b.lo[a]; maxs[i] = refs[i].b.hi[a]; }
+        std::sort(mins.begin(), mins.end());
+        std::sort(maxs.begin(), maxs.end());
+        auto consider = [&](float p) {
+            if (!(p > cell.lo[a]) || !(p < cell.hi[a])) return;
+            size_t nl = std::lower_bound(mins.begin(), mins.end(), p) - mins.begin();  // min < p
+            size_t nr = n - (std::upper_bound(maxs.begin(), maxs.end(), p) - maxs.begin());  // max > p
+            Box L = cell, R = cell;
+            L.hi[a] = p;
+            R.lo[a] = p;
+            float c = prm.cost_traverse + prm.cost_intersect * inv_area * (L.area() * (float)nl + R.area() * (float)nr);
+            if (nl == 0 || nr == 0) c *= prm.empty_bonus;
+            if (c < r.cost) { r.cost = c; r.pos = p; r.found = true; }
+        };
+        float last = NAN;
+        for (size_t i = 0; i < n; ++i) if (mins[i] != last) { last = mins[i]; consider(last); }
+        last = NAN;
+        for (size_t i = 0; i < n; ++i) if (maxs[i] != last) { last = maxs[i]; consider(last); }
+        return r;
+    }
+
+    bool best_split(const Box &cell, const std::vector<TriRef> &refs, int &axis_out, float &pos_out) {
+        const float leaf_cost = prm.cost_intersect * (float)refs.size();  // cost of not splitting
+        AxisBest ab[3];
+        if (tasks && refs.size() > 4096) {
+            std::thread t1([&] { ab[1] = best_on_axis(cell, refs, 1, leaf_cost); });
+            std::thread t2([&] { ab[2] = best_on_axis(cell, refs, 2, leaf_cost); });
+            ab[0] = best_on_axis(cell, refs, 0, leaf_cost);
+            t1.join();
+            t2.join();
+        } else {
+            for (int a = 0; a < 3; ++a) ab[a] = best_on_axis(cell, refs, a, leaf_cost);
         }
+        float best = leaf_cost;
+        bool found = false;
+        for (int a = 0; a < 3; ++a)
+            if (ab[a].found && ab[a].cost < best) { best = ab[a].cost; axis_out = a; pos_out = ab[a].pos; found = true; }
         return found;
     }
 
+    // Subtrees handed to worker threads: the top of the tree is built here, every subtree that has shrunk to
+    // `spawn_below` references becomes a task with its own Builder, and the task's nodes are spliced in
+    // afterwards.  Node numbers differ from a sequential build, the TREE does not (each subtree is a pure
+    // function of its cell and references), and the flattening numbers units breadth-first from the root,
+    // so the emitted arrays are identical for any thread count.
+    struct Task {
+        Box cell;
+        std::vector<TriRef> refs;
+        uint32_t depth = 0;
+        std::vector<BuildNode> nodes;  // result
+        int root = -1;
+        uint32_t depth_reached = 0;
+    };
+    std::vector<Task> *tasks = nullptr;  // non-null while building the top with spawning enabled
+    size_t spawn_below = 0;  // a subtree with at most this many references (and more than 256) becomes a task
+
     int build(const Box &cell, std::vector<TriRef> &refs, uint32_t depth) {
         depth_reached = std::max(depth_reached, depth);
+        if (tasks && depth >= 1 && refs.size() > 256 && refs.size() <= spawn_below) {
+            Task t;
+            t.cell = cell;
+            t.refs.swap(refs);
+            t.depth = depth;
+            tasks->push_back(std::move(t));
+            return -2 - (int)(tasks->size() - 1);  // placeholder, patched by splice()
+        }
         int axis = -1;
         float pos = 0.f;
         if (refs.size() <= prm.leaf_max || depth >= max_depth || !best_split(cell, refs, axis, pos))
@@ -110,6 +157,42 @@ struct Builder {
         nodes[self].left = l;
         nodes[self].right = r;
         return self;
+    }
+
+    void run_tasks(std::vector<Task> &ts, unsigned threads) {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i = next.fetch_add(1); i < ts.size(); i = next.fetch_add(1)) {
+                Builder sub(prm, 1);
+                sub.max_depth = max_depth;
+                ts[i].root = sub.build(ts[i].cell, ts[i].refs, ts[i].depth);
+                ts[i].nodes = std::move(sub.nodes);
+                ts[i].depth_reached = sub.depth_reached;
+            }
+        };
+        std::vector<std::thread> pool;
+        const unsigned n = (unsigned)std::min<size_t>(threads, ts.size());
+        for (unsigned k = 1; k < n; ++k) pool.emplace_back(worker);
+        worker();
+        for (std::thread &t : pool) t.join();
+    }
+
+    void splice(std::vector<Task> &ts) {
+        std::vector<int> root_of(ts.size());
+        for (size_t i = 0; i < ts.size(); ++i) {
+            const int off = (int)nodes.size();
+            for (BuildNode &n : ts[i].nodes) {
+                if (n.axis >= 0) { n.left += off; n.right += off; }
+                nodes.push_back(std::move(n));
+            }
+            root_of[i] = ts[i].root + off;
+            depth_reached = std::max(depth_reached, ts[i].depth_reached);
+        }
+        for (BuildNode &n : nodes) {
+            if (n.axis < 0) continue;
+            if (n.left <= -2) n.left = root_of[(size_t)(-2 - n.left)];
+            if (n.right <= -2) n.right = root_of[(size_t)(-2 - n.right)];
+        }
     }
 
     // Push a rope down to the deepest node whose cell still covers the whole face `f` of `box`.
@@ -179,10 +262,31 @@ FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t
         root.hi[a] += pad;
     }
 
+    const auto t_start = std::chrono::steady_clock::now();
     Builder b(params, nt);
-    const int root_node = b.build(root, refs, 0);
+    unsigned threads = params.threads ? params.threads : std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("HRT_KD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    threads = std::min(threads, 16u);  // measured on the MI355X host (pool flamingo, 31 575 triangles): 1 -> 273 ms, 4 -> 177, 16 -> 112, 64 -> 173
+    int root_node;
+    if (threads > 1 && nt > 4096) {
+        std::vector<Builder::Task> tasks;
+        b.tasks = &tasks;
+        b.spawn_below = std::max<size_t>(512, nt / (4u * threads));  // SAH first cuts empty space: split by size, not by depth
+        root_node = b.build(root, refs, 0);  // the root itself (depth 0) is never a task
+        b.tasks = nullptr;
+        const auto t_top = std::chrono::steady_clock::now();
+        b.run_tasks(tasks, threads);
+        b.splice(tasks);
+        if (std::getenv("HRT_KD_VERBOSE"))
+            std::fprintf(stderr, "kd build: top %.1f ms, %zu subtree tasks\n",
+                         std::chrono::duration<double, std::milli>(t_top - t_start).count(), tasks.size());
+    } else {
+        root_node = b.build(root, refs, 0);
+    }
+    const auto t_built = std::chrono::steady_clock::now();
     const int nil[6] = {-1, -1, -1, -1, -1, -1};
     b.assign_ropes(root_node, nil);
+    const auto t_roped = std::chrono::steady_clock::now();
 
     // Breadth-first numbering in 16-byte units: inner = 1 unit, leaf = 4 units.
     std::vector<int> order;
@@ -229,6 +333,11 @@ FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t
     out.root = ref_of(root_node);
     for (int a = 0; a < 3; ++a) { out.root_lo[a] = root.lo[a]; out.root_hi[a] = root.hi[a]; }
     out.depth = b.depth_reached;
+    if (std::getenv("HRT_KD_VERBOSE")) {
+        auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+        std::fprintf(stderr, "kd build: %u triangles, %u threads: tree %.1f ms, ropes %.1f ms, flatten %.1f ms\n", nt, threads,
+                     ms(t_start, t_built), ms(t_built, t_roped), ms(t_roped, std::chrono::steady_clock::now()));
+    }
     return out;
 }
 

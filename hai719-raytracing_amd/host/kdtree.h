@@ -20,6 +20,7 @@ struct KDBuildParams {
     float cost_traverse = 1.0f;
     float cost_intersect = 1.5f;
     float empty_bonus = 0.8f;   // SAH multiplier when one side is empty
+    uint32_t threads = 0;       // worker threads for the subtrees below depth 5; 0 = hardware_concurrency (HRT_KD_THREADS overrides)
 };
 
 struct FlatKDTree {

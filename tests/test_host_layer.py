@@ -256,3 +256,22 @@ def test_demo_scenes_build_and_their_meshes_walk_exactly(hrt, oracle, name):
         assert np.array_equal(brute, rope), (name, m)
     img = oracle.OracleScene(desc).render(cam, 32, 18, 1, seed=1, threads=0)
     assert np.isfinite(img).all() and img.max() > 0
+
+
+def test_threaded_kd_build_emits_the_same_tree(hrt, monkeypatch):
+    """the SAH build hands subtrees to worker threads (and the three axes of a big node's split
+    search to three); the flattened nodelets and leaf lists must not depend on the thread count."""
+    def tree(threads):
+        monkeypatch.setenv("HRT_KD_THREADS", str(threads))
+        host = hrt.HostScene().setup("flamingo_lake", 16 / 9, 1)  # 31 575 triangles
+        desc = host.flatten()
+        d = C.cast(desc, C.POINTER(SceneDesc)).contents
+        m = C.cast(d.meshes, C.POINTER(MeshDesc))[0]
+        units = np.ctypeslib.as_array(C.cast(m.kd_units, C.POINTER(C.c_uint32)), shape=(m.n_kd_units * 4,)).copy()
+        leaves = np.ctypeslib.as_array(C.cast(m.leaf_tris, C.POINTER(C.c_uint32)), shape=(m.n_leaf_tris,)).copy()
+        return units, leaves, m.kd_root
+    u1, l1, r1 = tree(1)
+    for threads in (2, 5):
+        u, l, r = tree(threads)
+        assert r == r1 and np.array_equal(u, u1) and np.array_equal(l, l1)
+    assert len(u1) > 100000
