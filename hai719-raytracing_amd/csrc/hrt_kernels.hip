@@ -1,4 +1,7 @@
-// Hand-written HIP kernels of the trace path for gfx950 (CDNA4, wave64).
+// Hand-written HIP kernels of the trace path for gfx950 (CDNA4, wave64): the exact-arithmetic device functions every
+// kernel form shares (intersectors, KD walk, shading, scattering, camera) and the lane-per-pixel kernel.
+// hrt_stream.hip (workgroup-streaming kernel, the default for scenes with meshes or lights) and hrt_dual.hip (two
+// pixel streams per lane) schedule the same functions differently.
 //
 // hrt_trace_kernel is the persistent-wavefront megakernel: every wave pulls 8x8-pixel tiles from a
 // work-queue head, lane = pixel, and each lane runs the reference's per-sample loop
