@@ -191,6 +191,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 
 #ifdef HRT_SP_DEBUG
     unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0;
+    unsigned long long dbg_class[6] = {0, 0, 0, 0, 0, 0};  // clocks in T, mesh-hit, sphere-hit, square-hit, miss, G chunks
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
 #endif
     for (;;) {  // tiles
@@ -266,6 +267,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     if (c >= total) break;
 #ifdef HRT_SP_DEBUG
                     ++dbg_chunks;
+                    const unsigned long long dbg_c0 = __builtin_readcyclecounter();
+                    const uint32_t dbg_k = c < nT ? 0u : (c < e3 ? 1u : (c < e1 ? 2u : (c < e2 ? 3u : (c < e0 ? 4u : 5u))));
 #endif
                     if (c < nT) {
                         // ---------------- T: mesh walk
@@ -384,6 +387,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         sp_push_hit(L, C, parity ^ 1u, trace && !to_mesh, kind, slot);
                         sp_push(qFo, cFo, freed, slot);
                     }
+#ifdef HRT_SP_DEBUG
+                    dbg_class[dbg_k] += __builtin_readcyclecounter() - dbg_c0;
+#endif
                 }
 #ifdef HRT_SP_DEBUG
                 dbg_work += __builtin_readcyclecounter() - dbg_w0;
@@ -416,6 +422,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     if (lane == 0 && R.stamps) {  // per-wave sums: [0] clocks in chunk loops, [1] clocks alive, [2] cycles, [3] chunks, [4] clocks in the serial section
         atomicAdd(R.stamps + 0, dbg_work); atomicAdd(R.stamps + 1, __builtin_readcyclecounter() - dbg_t0);
         atomicAdd(R.stamps + 2, dbg_cycles); atomicAdd(R.stamps + 3, dbg_chunks); atomicAdd(R.stamps + 4, dbg_serial);
+        for (int k = 0; k < 6; ++k) atomicAdd(R.stamps + 5 + k, dbg_class[k]);  // [5..10] clocks per chunk class
     }
 #endif
 #undef SP_UNI
