@@ -397,18 +397,13 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
         // in index order with the reference's strict `<`, so the selected hit is the reference's.
         uint64_t cand = 0ull;
         float tsure = h.t;  // upper bound on the exact t of a hit that certainly exists
-        // rows of quad i+1 are requested before quad i is evaluated, so the scalar-load latency
-        // (s_load_dwordx4 x4) overlaps ~45 VALU instructions instead of stalling every trip
-        float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-        if (nq) { n0 = ld(qd, 0); n1 = ld(qd, 1); n2 = ld(qd, 2); n3 = ld(qd, 3); }
-        for (uint32_t i = 0; i < nq; ++i) {
-            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            if (i + 1 < nq) {
-                n0 = ld(qd, HRT_QUAD_ROWS * (i + 1)); n1 = ld(qd, HRT_QUAD_ROWS * (i + 1) + 1);
-                n2 = ld(qd, HRT_QUAD_ROWS * (i + 1) + 2); n3 = ld(qd, HRT_QUAD_ROWS * (i + 1) + 3);
-            }
+        // Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are already in
+        // flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
+        // load latency overlaps the ~45 VALU instructions of a quad and no row is ever copied (a rolling single-set
+        // prefetch costs 16 s_mov per quad, as many issue slots as a third of the filter).
+        auto filter = [&](uint32_t i, const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3) {
             const uint32_t flags = __float_as_uint(q1.w);
-            if (flags & HRT_QUAD_FLAG_MOVING) { cand |= 1ull << i; continue; }  // uniform branch; the exact path decides
+            if (flags & HRT_QUAD_FLAG_MOVING) { cand |= 1ull << i; return; }  // uniform branch; the exact path decides
             const f3 n = mk(q1);
             const float dotRN = dot(ray.d, n);                    // exact: the sign tests are the reference's
             const bool front = (flags & HRT_QUAD_FLAG_GLASS) ? (dotRN != 0.f) : (dotRN < 0.f);
@@ -425,6 +420,23 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
             const bool sure = front && ta >= 1.1e-5f && x1 >= m1 && x1 <= s1 - m1 && x2 >= m2 && x2 <= s2 - m2;
             if (loose) cand |= 1ull << i;
             if (sure) tsure = fminf(tsure, ta * (1.f + 1e-6f));
+        };
+        float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;
+        if (nq > 0u) { a0 = ld(qd, 0); a1 = ld(qd, 1); a2 = ld(qd, 2); a3 = ld(qd, 3); }
+        if (nq > 1u) { b0 = ld(qd, HRT_QUAD_ROWS); b1 = ld(qd, HRT_QUAD_ROWS + 1); b2 = ld(qd, HRT_QUAD_ROWS + 2); b3 = ld(qd, HRT_QUAD_ROWS + 3); }
+        for (uint32_t i = 0; i < nq; i += 2u) {
+            filter(i, a0, a1, a2, a3);
+            if (i + 2u < nq) {
+                a0 = ld(qd, HRT_QUAD_ROWS * (i + 2u)); a1 = ld(qd, HRT_QUAD_ROWS * (i + 2u) + 1);
+                a2 = ld(qd, HRT_QUAD_ROWS * (i + 2u) + 2); a3 = ld(qd, HRT_QUAD_ROWS * (i + 2u) + 3);
+            }
+            if (i + 1u < nq) {
+                filter(i + 1u, b0, b1, b2, b3);
+                if (i + 3u < nq) {
+                    b0 = ld(qd, HRT_QUAD_ROWS * (i + 3u)); b1 = ld(qd, HRT_QUAD_ROWS * (i + 3u) + 1);
+                    b2 = ld(qd, HRT_QUAD_ROWS * (i + 3u) + 2); b3 = ld(qd, HRT_QUAD_ROWS * (i + 3u) + 3);
+                }
+            }
         }
         STAMP(2);
         gf4 gq = (gf4)S->quads;
