@@ -250,6 +250,11 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         quads.push_back(make_float4(m.motion[0], m.motion[1], m.motion[2], as_float((uint32_t)q.material)));
         quads.push_back(make_float4(q.tangent[0], q.tangent[1], q.tangent[2], 0.f));
         quads.push_back(make_float4(q.bitangent[0], q.bitangent[1], q.bitangent[2], 0.f));
+        // the filter's copy (hrt_device.h): values identical to the rows above, only their order differs
+        quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
+        quads.push_back(make_float4(n.y, n.z, n.x, as_float(flags)));
+        quads.push_back(make_float4(R.x, U.x, R.y, U.y));
+        quads.push_back(make_float4(R.z, U.z, h_len(R), h_len(U)));
     }
     for (uint32_t i = 0; i < D.n_lights; ++i) {
         const hrt_light &l = D.lights[i];

@@ -9,6 +9,8 @@
 //     sphere  2 rows: {c.xyz, r} {motion.xyz, material}
 //     quad    5 rows: {p0.xyz, D0} {n.xyz, flags} {R.xyz, |R|} {U.xyz, |U|} {motion.xyz, material}
 //             + 2 rows used only when shading: {T.xyz,0} {B.xyz,0}
+//             + 4 rows for the filter, laid out as the SGPR pairs its packed-fp32 instructions take:
+//               {p0.xyz, D0} {n.y, n.z, n.x, flags} {R.x, U.x, R.y, U.y} {R.z, U.z, |R|, |U|}
 //   materials     6 float4 rows per material, read per lane at the closest hit
 //   meshes        DMesh records (wave-uniform)
 //   kd units      uint4 nodelets (include/hrt.h), refs rebased to the global array
@@ -23,7 +25,8 @@
 
 #include "../../include/hrt.h"
 
-#define HRT_QUAD_ROWS 7
+#define HRT_QUAD_ROWS 11
+#define HRT_QUAD_FROW 7   // first of the four rows the no-division filter reads (one s_load_dwordx16)
 #define HRT_SPHERE_ROWS 2
 #define HRT_MAT_ROWS 6
 #define HRT_TRI_ROWS 5
