@@ -376,6 +376,58 @@ __device__ __forceinline__ f3 ray_inv(const Ray &ray) {
     return mk(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
 }
 
+// The no-division FILTER over the squares (wave-uniform loop, scalar rows): bit i of the result = square i can possibly
+// be the closest accepted hit (see prims_hit).  M = uint32_t for up to 32 squares (the per-lane mask costs half the VALU
+// work of a 64-bit one), uint64_t for up to 64.
+template <class M>
+__device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, uint32_t nq, float tsure) {
+    M cand = 0;
+    // Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are already in
+    // flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
+    // load latency overlaps the ~45 VALU instructions of a quad and no row is ever copied (a rolling single-set
+    // prefetch costs 16 s_mov per quad, as many issue slots as a third of the filter).
+    // f0 {p0.xyz, D0}  f1 {n.y, n.z, n.x, flags}  f2 {R.x, U.x, R.y, U.y}  f3 {R.z, U.z, |R|, |U|}: the (R, U) and (n.y, n.z)
+    // pairs sit in aligned SGPR pairs, which is how v_pk_mul/fma_f32 take them -- no scalar moves after the load.
+    auto filter = [&](uint32_t i, const float4 &f0, const float4 &f1, const float4 &f2, const float4 &f3) {
+        const uint32_t flags = __float_as_uint(f1.w);
+        if (flags & HRT_QUAD_FLAG_MOVING) { cand |= (M)1 << i; return; }  // uniform branch; the exact path decides
+        const float dotRN = ray.d.x * f1.z + ray.d.y * f1.x + ray.d.z * f1.y;  // exact, Vec3.h:48 order: the sign tests are the reference's
+        const bool front = (dotRN < 0.f) || ((flags & HRT_QUAD_FLAG_GLASS) && dotRN > 0.f);
+        const float num = f0.w - (ray.o.x * f1.z + ray.o.y * f1.x + ray.o.z * f1.y);  // exact numerator
+        const float ta = num * __builtin_amdgcn_rcpf(dotRN);  // |ta - fl(num/dotRN)| <= 4e-7 |t|
+        const float ax = __builtin_fmaf(ta, ray.d.x, ray.o.x) - f0.x, ay = __builtin_fmaf(ta, ray.d.y, ray.o.y) - f0.y,
+                    az = __builtin_fmaf(ta, ray.d.z, ray.o.z) - f0.z;
+        const float x1 = __builtin_fmaf(az, f3.x, __builtin_fmaf(ay, f2.z, ax * f2.x));
+        const float x2 = __builtin_fmaf(az, f3.y, __builtin_fmaf(ay, f2.w, ax * f2.y));
+        const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);  // bound on |p' - p|, generous
+        const float m1 = f3.z * e, m2 = f3.w * e, s1 = f3.z * f3.z, s2 = f3.w * f3.w;
+        const bool loose = front && ta >= 9e-6f && ta * (1.f - 1e-6f) <= tsure && x1 >= -m1 && x1 <= s1 + m1 && x2 >= -m2 &&
+                           x2 <= s2 + m2;
+        const bool sure = front && ta >= 1.1e-5f && x1 >= m1 && x1 <= s1 - m1 && x2 >= m2 && x2 <= s2 - m2;
+        if (loose) cand |= (M)1 << i;
+        if (sure) tsure = fminf(tsure, ta * (1.f + 1e-6f));
+    };
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;
+    cf4 fr = qd + HRT_QUAD_FROW;
+    if (nq > 0u) { a0 = ld(fr, 0); a1 = ld(fr, 1); a2 = ld(fr, 2); a3 = ld(fr, 3); }
+    if (nq > 1u) { b0 = ld(fr, HRT_QUAD_ROWS); b1 = ld(fr, HRT_QUAD_ROWS + 1); b2 = ld(fr, HRT_QUAD_ROWS + 2); b3 = ld(fr, HRT_QUAD_ROWS + 3); }
+    for (uint32_t i = 0; i < nq; i += 2u) {
+        filter(i, a0, a1, a2, a3);
+        if (i + 2u < nq) {
+            a0 = ld(fr, HRT_QUAD_ROWS * (i + 2u)); a1 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 1);
+            a2 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 2); a3 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 3);
+        }
+        if (i + 1u < nq) {
+            filter(i + 1u, b0, b1, b2, b3);
+            if (i + 3u < nq) {
+                b0 = ld(fr, HRT_QUAD_ROWS * (i + 3u)); b1 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 1);
+                b2 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 2); b3 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 3);
+            }
+        }
+    }
+    return cand;
+}
+
 // Spheres then squares of Scene::computeIntersection (Scene.h:207-221).
 __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
     cscene S = cx.S;
@@ -395,51 +447,8 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
         // conservative error margins decide which quads can possibly be the closest accepted hit.
         // REFINE: only those (usually one per lane) go through the exact Square::intersect arithmetic,
         // in index order with the reference's strict `<`, so the selected hit is the reference's.
-        uint64_t cand = 0ull;
-        float tsure = h.t;  // upper bound on the exact t of a hit that certainly exists
-        // Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are already in
-        // flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
-        // load latency overlaps the ~45 VALU instructions of a quad and no row is ever copied (a rolling single-set
-        // prefetch costs 16 s_mov per quad, as many issue slots as a third of the filter).
-        // f0 {p0.xyz, D0}  f1 {n.y, n.z, n.x, flags}  f2 {R.x, U.x, R.y, U.y}  f3 {R.z, U.z, |R|, |U|}: the (R, U) and (n.y, n.z)
-        // pairs sit in aligned SGPR pairs, which is how v_pk_mul/fma_f32 take them -- no scalar moves after the load.
-        auto filter = [&](uint32_t i, const float4 &f0, const float4 &f1, const float4 &f2, const float4 &f3) {
-            const uint32_t flags = __float_as_uint(f1.w);
-            if (flags & HRT_QUAD_FLAG_MOVING) { cand |= 1ull << i; return; }  // uniform branch; the exact path decides
-            const float dotRN = ray.d.x * f1.z + ray.d.y * f1.x + ray.d.z * f1.y;  // exact, Vec3.h:48 order: the sign tests are the reference's
-            const bool front = (dotRN < 0.f) || ((flags & HRT_QUAD_FLAG_GLASS) && dotRN > 0.f);
-            const float num = f0.w - (ray.o.x * f1.z + ray.o.y * f1.x + ray.o.z * f1.y);  // exact numerator
-            const float ta = num * __builtin_amdgcn_rcpf(dotRN);  // |ta - fl(num/dotRN)| <= 4e-7 |t|
-            const float ax = __builtin_fmaf(ta, ray.d.x, ray.o.x) - f0.x, ay = __builtin_fmaf(ta, ray.d.y, ray.o.y) - f0.y,
-                        az = __builtin_fmaf(ta, ray.d.z, ray.o.z) - f0.z;
-            const float x1 = __builtin_fmaf(az, f3.x, __builtin_fmaf(ay, f2.z, ax * f2.x));
-            const float x2 = __builtin_fmaf(az, f3.y, __builtin_fmaf(ay, f2.w, ax * f2.y));
-            const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);  // bound on |p' - p|, generous
-            const float m1 = f3.z * e, m2 = f3.w * e, s1 = f3.z * f3.z, s2 = f3.w * f3.w;
-            const bool loose = front && ta >= 9e-6f && ta * (1.f - 1e-6f) <= tsure && x1 >= -m1 && x1 <= s1 + m1 && x2 >= -m2 &&
-                               x2 <= s2 + m2;
-            const bool sure = front && ta >= 1.1e-5f && x1 >= m1 && x1 <= s1 - m1 && x2 >= m2 && x2 <= s2 - m2;
-            if (loose) cand |= 1ull << i;
-            if (sure) tsure = fminf(tsure, ta * (1.f + 1e-6f));
-        };
-        float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;
-        cf4 fr = qd + HRT_QUAD_FROW;
-        if (nq > 0u) { a0 = ld(fr, 0); a1 = ld(fr, 1); a2 = ld(fr, 2); a3 = ld(fr, 3); }
-        if (nq > 1u) { b0 = ld(fr, HRT_QUAD_ROWS); b1 = ld(fr, HRT_QUAD_ROWS + 1); b2 = ld(fr, HRT_QUAD_ROWS + 2); b3 = ld(fr, HRT_QUAD_ROWS + 3); }
-        for (uint32_t i = 0; i < nq; i += 2u) {
-            filter(i, a0, a1, a2, a3);
-            if (i + 2u < nq) {
-                a0 = ld(fr, HRT_QUAD_ROWS * (i + 2u)); a1 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 1);
-                a2 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 2); a3 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 3);
-            }
-            if (i + 1u < nq) {
-                filter(i + 1u, b0, b1, b2, b3);
-                if (i + 3u < nq) {
-                    b0 = ld(fr, HRT_QUAD_ROWS * (i + 3u)); b1 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 1);
-                    b2 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 2); b3 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 3);
-                }
-            }
-        }
+        const float tsure = h.t;  // upper bound on the exact t of a hit that certainly exists
+        uint64_t cand = nq <= 32u ? (uint64_t)quad_filter<uint32_t>(cx, ray, qd, nq, tsure) : quad_filter<uint64_t>(cx, ray, qd, nq, tsure);
         STAMP(2);
         gf4 gq = (gf4)S->quads;
         while (cand) {
