@@ -126,7 +126,8 @@ __device__ __forceinline__ void ds_fresh(PathState &p, bool live) {
 
 // Up to `trips` trips of the walk of mesh M (mesh_traverse's loop body, KDTree.cpp:31-85 semantics);
 // true when the walk is complete: w.best_* then hold the mesh's closest triangle with t >= 0, if any.
-__device__ __forceinline__ bool mesh_walk(const Ctx &cx, cmesh M, const Ray &ray, f3 inv, Walk &w, int trips) {
+template <class MP>  // cmesh: wave-uniform mesh, scalar record loads; gmesh: every lane its own mesh, vector loads
+__device__ __forceinline__ bool mesh_walk(const Ctx &cx, MP M, const Ray &ray, f3 inv, Walk &w, int trips) {
     if (w.ref == HRT_KD_NIL) {  // start: clip the ray to the root cell
         float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
         float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
@@ -237,6 +238,25 @@ __device__ __forceinline__ bool walk_some(const Ctx &cx, const Ray &ray, uint32_
                 parked &= ~(1u << i);
             }
         }
+    }
+    return parked == 0u;
+}
+
+// The same with every lane on ITS next mesh at once (per-lane mesh records): lanes that wait for different meshes
+// of a multi-mesh scene walk in the same trips instead of taking turns.  Results cannot differ: a walk depends
+// only on its ray and its mesh.
+typedef const DMesh __attribute__((address_space(1))) *gmesh;
+__device__ __forceinline__ bool walk_some_per_lane(const Ctx &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
+    const f3 inv = ray_inv(ray);
+    gmesh meshes = (gmesh)cx.S->meshes;
+    while (parked != 0u) {
+        const uint32_t i = (uint32_t)__builtin_ctz(parked);
+        if (!mesh_walk(cx, meshes + i, ray, inv, w, trips)) break;  // out of trips: resume here next visit
+        const float t = w.best_t;
+        if (t < HRT_FLT_MAX && t < h.t && HRT_T_ACCEPT(t)) {
+            h.kind = 3; h.index = i; h.t = t; h.tri = w.best_tri; h.a0 = w.bu; h.a1 = w.bv;
+        }
+        parked &= parked - 1u;
     }
     return parked == 0u;
 }

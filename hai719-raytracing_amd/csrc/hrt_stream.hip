@@ -185,6 +185,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     }
     for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 3, 0)[i] = (uint16_t)i;  // every slot free
     const bool has_mesh = cx.S->n_meshes != 0u;
+    const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
     float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNIT * 3u);
     const uint32_t glog = R.sp_group_log2, G = 1u << glog, upix = 64u << glog;  // tiles and pixels per unit
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
@@ -286,7 +287,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
                             w.bv = spf(L, SP_WBV, slot);
                             const uint32_t pm_in = pm;
-                            walked = walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
+                            walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
                             if (pm != pm_in) sp_store_hit(L, slot, h, pm);  // a mesh was finished: the best hit may have changed
                             if (!walked) {  // the state of the walk in progress (the next bounce starts from SP_WREF = NIL)
                                 spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
