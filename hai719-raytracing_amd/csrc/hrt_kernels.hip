@@ -411,6 +411,9 @@ __device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, 
     cf4 fr = qd + HRT_QUAD_FROW;
     if (nq > 0u) { a0 = ld(fr, 0); a1 = ld(fr, 1); a2 = ld(fr, 2); a3 = ld(fr, 3); }
     if (nq > 1u) { b0 = ld(fr, HRT_QUAD_ROWS); b1 = ld(fr, HRT_QUAD_ROWS + 1); b2 = ld(fr, HRT_QUAD_ROWS + 2); b3 = ld(fr, HRT_QUAD_ROWS + 3); }
+#ifdef HRT_FILTER_UNROLL
+#pragma unroll HRT_FILTER_UNROLL
+#endif
     for (uint32_t i = 0; i < nq; i += 2u) {
         filter(i, a0, a1, a2, a3);
         if (i + 2u < nq) {
