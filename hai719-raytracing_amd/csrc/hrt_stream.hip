@@ -400,14 +400,33 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             }
             // the chunk has drained: fold its samples into the pixel sums in sample order (main.cpp:193)
             __syncthreads();
+#ifdef HRT_SP_FOLD_ATOMIC
             for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {  // i = pixel-of-unit * 3 + channel
                 float acc = L.run[i];
-                // agent-scope relaxed loads (global_load ... sc1): served by L2, never by a stale L1 line of an
-                // earlier chunk that other waves of this workgroup have since overwritten
                 for (uint32_t s = 0; s < ns; ++s)
                     acc += __hip_atomic_load(scratch + (size_t)s * (upix * 3u) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 L.run[i] = acc;
             }
+#else
+            // One agent-scope acquire drops this CU's L1 lines (an earlier unit's fold may have left stale copies of
+            // the scratch other waves have since overwritten); the loads below are then plain and pipeline freely.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {  // i = pixel-of-unit * 3 + channel
+                float acc = L.run[i];
+                const float *col = scratch + i;
+                const uint32_t stride = upix * 3u;
+                uint32_t s = 0;
+                for (; s + 8u <= ns; s += 8u) {  // 8 loads in flight, added in sample order
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = col[(size_t)(s + k) * stride];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc += v[k];
+                }
+                for (; s < ns; ++s) acc += col[(size_t)s * stride];
+                L.run[i] = acc;
+            }
+#endif
         }
         __syncthreads();
         for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {
