@@ -403,9 +403,10 @@ __device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, 
         const float m1 = f3.z * e, m2 = f3.w * e, s1 = f3.z * f3.z, s2 = f3.w * f3.w;
         const bool loose = front && ta >= 9e-6f && ta * (1.f - 1e-6f) <= tsure && x1 >= -m1 && x1 <= s1 + m1 && x2 >= -m2 &&
                            x2 <= s2 + m2;
-        const bool sure = front && ta >= 1.1e-5f && x1 >= m1 && x1 <= s1 - m1 && x2 >= m2 && x2 <= s2 - m2;
         if (loose) cand |= (M)1 << i;
-        if (sure) tsure = fminf(tsure, ta * (1.f + 1e-6f));
+        // (A second, strict test used to shrink `tsure` to the nearest square that is certainly hit, so that squares
+        // behind it were not refined.  It cost 11 VALU per square and saved a second refinement on ~5 % of the rays:
+        // dropping it is 1-4 % faster on every scene.)
     };
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;
     cf4 fr = qd + HRT_QUAD_FROW;
