@@ -392,7 +392,8 @@ __device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, 
         const uint32_t flags = __float_as_uint(f1.w);
         if (flags & HRT_QUAD_FLAG_MOVING) { cand |= (M)1 << i; return; }  // uniform branch; the exact path decides
         const float dotRN = ray.d.x * f1.z + ray.d.y * f1.x + ray.d.z * f1.y;  // exact, Vec3.h:48 order: the sign tests are the reference's
-        const bool front = (dotRN < 0.f) || ((flags & HRT_QUAD_FLAG_GLASS) && dotRN > 0.f);
+        const bool glass = (flags & HRT_QUAD_FLAG_GLASS) != 0u;
+        const bool front = (dotRN < 0.f) | (glass & (dotRN > 0.f));  // `|`, `&`: lane masks combined, no short-circuit branches
         const float num = f0.w - (ray.o.x * f1.z + ray.o.y * f1.x + ray.o.z * f1.y);  // exact numerator
         const float ta = num * __builtin_amdgcn_rcpf(dotRN);  // |ta - fl(num/dotRN)| <= 4e-7 |t|
         const float ax = __builtin_fmaf(ta, ray.d.x, ray.o.x) - f0.x, ay = __builtin_fmaf(ta, ray.d.y, ray.o.y) - f0.y,
@@ -401,8 +402,8 @@ __device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, 
         const float x2 = __builtin_fmaf(az, f3.y, __builtin_fmaf(ay, f2.w, ax * f2.y));
         const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);  // bound on |p' - p|, generous
         const float m1 = f3.z * e, m2 = f3.w * e, s1 = f3.z * f3.z, s2 = f3.w * f3.w;
-        const bool loose = front && ta >= 9e-6f && ta * (1.f - 1e-6f) <= tsure && x1 >= -m1 && x1 <= s1 + m1 && x2 >= -m2 &&
-                           x2 <= s2 + m2;
+        const bool loose = front & (ta >= 9e-6f) & (ta * (1.f - 1e-6f) <= tsure) & (x1 >= -m1) & (x1 <= s1 + m1) & (x2 >= -m2) &
+                           (x2 <= s2 + m2);
         if (loose) cand |= (M)1 << i;
         // (A second, strict test used to shrink `tsure` to the nearest square that is certainly hit, so that squares
         // behind it were not refined.  It cost 11 VALU per square and saved a second refinement on ~5 % of the rays:
