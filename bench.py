@@ -13,6 +13,8 @@ samples per pixel grow as 256*N so every GPU traces the same 530.8 M samples as 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+(HRT_BENCH_SHARE_GPU=1 rehearses the N > 1 path on a one-GPU box: all ranks share GPU 0, collectives over gloo.)
+
 Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel's algorithmic bytes (SURVEY.md
 8(d) record sizes x committed per-sample work counters) against the 8 TB/s HBM peak, with the
 kernel's launch duration measured by HIP events on the launch stream.  `cpu_baseline` is the CPU
@@ -99,15 +101,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One rank per GPU.  HRT_BENCH_SHARE_GPU=1 is a rehearsal mode for a one-GPU box: all ranks share GPU 0 and the
+    # collectives run over gloo (staged through host memory), which exercises everything but RCCL itself.
+    share = os.environ.get("HRT_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     hrt = importlib.import_module("hai719-raytracing_amd")
     hdist = importlib.import_module("hai719-raytracing_amd.dist")
-    hrt.init(local_rank)
+    hrt.init(dev_index)
 
     spp = args.spp * world  # weak scaling: per-GPU samples stay w*h*args.spp
     host = hrt.HostScene().setup(SCENE, W / H, 1)
@@ -139,7 +148,7 @@ def main():
         kernel_ms.append(scene.last_kernel_ms())  # HIP events on the launch stream (blocks on this step's kernel)
     sync()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

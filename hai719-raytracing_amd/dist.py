@@ -38,11 +38,20 @@ def render_frame_distributed(render_tiles: Callable, w: int, h: int, rank: int, 
     if world == 1:
         gathered = mine.unsqueeze(0)
     else:
-        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gather_list=bufs, dst=0)
-        if rank != 0:
-            return None
-        gathered = torch.stack(bufs, dim=0)
+        if dist.get_backend() == "gloo" and mine.is_cuda:  # gloo has no device gather: stage through host memory
+            torch.cuda.current_stream().synchronize()
+            host = mine.cpu()
+            bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, gather_list=bufs, dst=0)
+            if rank != 0:
+                return None
+            gathered = torch.stack(bufs, dim=0).to(device)
+        else:
+            bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, gather_list=bufs, dst=0)
+            if rank != 0:
+                return None
+            gathered = torch.stack(bufs, dim=0)
     if on_gpu:
         frame = torch.empty((h, w, 3), dtype=torch.float32, device=device)
         assemble_frame(gathered.data_ptr(), per_rank, w, h, world, frame.data_ptr(), stream_ptr)
