@@ -284,15 +284,18 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             uint32_t pm = spu(L, SP_PM, slot);
                             Walk w;
                             w.ref = spu(L, SP_WREF, slot); w.t_entry = spf(L, SP_WTE, slot); w.kk = spu(L, SP_WKK, slot);
+                            const uint32_t ref_in = w.ref;
                             w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
                             w.bv = spf(L, SP_WBV, slot);
                             const uint32_t pm_in = pm;
                             walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
                             if (pm != pm_in) sp_store_hit(L, slot, h, pm);  // a mesh was finished: the best hit may have changed
-                            if (!walked) {  // the state of the walk in progress (the next bounce starts from SP_WREF = NIL)
+                            if (!walked) {  // the state of the walk in progress
                                 spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
                                 spf(L, SP_WBT, slot) = w.best_t; spu(L, SP_WTRI, slot) = w.best_tri; spf(L, SP_WBU, slot) = w.bu;
                                 spf(L, SP_WBV, slot) = w.bv;
+                            } else if (ref_in != HRT_KD_NIL) {
+                                spu(L, SP_WREF, slot) = HRT_KD_NIL;  // invariant: SP_WREF is NIL whenever the path is not in a T queue
                             }
                             kind = h.kind;
                         }
@@ -380,7 +383,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             const uint32_t pm = has_mesh ? mesh_gates(cx, ray) : 0u;
                             sp_store_ray(L, slot, ray);
                             sp_store_hit(L, slot, h, pm);
-                            spu(L, SP_WREF, slot) = HRT_KD_NIL;  // no walk in progress
+                            if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
                             to_mesh = pm != 0u;
                             kind = h.kind;
                         }
