@@ -58,10 +58,12 @@
 namespace hrtk {
 
 // One path = one 128-byte record.  Dwords 0-19 are what a T visit touches (ray, best hit, meshes to walk, walk
-// state: five aligned 16-byte groups), 0-11 and 20-31 what a hit / new-path visit touches.
+// state: five aligned 16-byte groups), 0-11 and 20-31 what a hit / new-path visit touches (it writes back 0-11 and 24-31).
 enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_HT, SP_HID, SP_HA0, SP_HA1, SP_HTRI, SP_PM,
        SP_WREF, SP_WTE, SP_WKK, SP_WBT, SP_WTRI, SP_WBU, SP_WBV, SP_PAD,
-       SP_TM, SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB, SP_K0, SP_K1, SP_RI, SP_N, SP_REM, SP_FIELDS };  // 32 dwords: one 128-byte record
+       SP_TM, SP_K0, SP_K1, SP_N,                            // written once, when the path starts
+       SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB, SP_RI, SP_REM,  // rewritten by every hit visit: two aligned 16-byte stores
+       SP_FIELDS };  // 32 dwords: one 128-byte record
 
 struct SpCtl {           // control block in LDS (20 dwords)
     uint32_t cT[2], cF[2];   // queue fills, [parity]
