@@ -120,3 +120,20 @@ def test_encoder_rejects_a_buffer_that_is_too_small(gpu):
         gpu.encode_ppm(t.data_ptr(), 4, 4, 3, out.data_ptr(), 16, 0)
     with pytest.raises(gpu.HrtError):
         gpu.encode_ppm(t.data_ptr(), 4, 4, 5, out.data_ptr(), 16, 0)
+
+
+def test_raytracer_driver_writes_the_file_the_library_renders(gpu, tmp_path):
+    """host/raytracer_main.cpp is the reference's `'r'` key without GLUT: scene set-up, flatten,
+    hrt_render with gamma, P3 dump.  Its file must be the bytes of the same render through the Python binding."""
+    import os
+    import subprocess
+    from conftest import PKG, ROOT
+    w, h, spp, seed = 96, 54, 3, 5
+    out = tmp_path / "rendu.ppm"
+    exe = os.path.join(PKG, "raytracer")
+    r = subprocess.run([exe, "--scene", "cornell_mesh", "--w", str(w), "--h", str(h), "--spp", str(spp), "--seed", str(seed),
+                        "--assets", os.path.join(ROOT, "assets"), "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    desc, dev, cam = build(gpu, "cornell_mesh", w / h)
+    img, _ = dev.render(cam, w, h, spp, seed=seed, flags=gpu.FLAG_GAMMA)
+    assert out.read_bytes() == gpu.ppm_text_reference(img)
