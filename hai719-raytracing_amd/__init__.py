@@ -112,6 +112,7 @@ def host_lib() -> C.CDLL:
         lib.hrt_host_scene_clear.argtypes = [C.c_void_p]
         lib.hrt_host_scene_add_texture.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         lib.hrt_host_scene_add_normal_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        lib.hrt_host_scene_set_skybox.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         lib.hrt_host_scene_add_sphere.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(Material)]
         lib.hrt_host_scene_add_quad.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(Material)]
@@ -228,6 +229,15 @@ class HostScene:
 
     def add_light(self, pos, radius, color=(1, 1, 1)):
         self._check(self._lib.hrt_host_scene_add_light(self._h, _fp(pos), radius, _fp(color)))
+
+    def set_skybox(self, rgb: Optional[np.ndarray]):
+        """Equirectangular RGB8 skybox (h, w, 3), or None to remove it (Scene::loadSkybox, from memory)."""
+        if rgb is None:
+            self._check(self._lib.hrt_host_scene_set_skybox(self._h, 0, 0, None))
+            return
+        a = np.ascontiguousarray(rgb, dtype=np.uint8)
+        self._keep.append(a)
+        self._check(self._lib.hrt_host_scene_set_skybox(self._h, a.shape[1], a.shape[0], a.ctypes.data))
 
     def set_sky(self, dark: bool):
         self._check(self._lib.hrt_host_scene_set_sky(self._h, int(dark)))

@@ -101,6 +101,13 @@ int hrt_host_scene_add_normal_map(hrt_host_scene *s, int32_t w, int32_t h, const
     return (int)s->scene.normals.size() - 1;
 }
 
+int hrt_host_scene_set_skybox(hrt_host_scene *s, int32_t w, int32_t h, const uint8_t *rgb) {
+    if (!s) return fail(HRT_ERR_INVALID, "set_skybox: NULL scene");
+    if (!rgb || w < 1 || h < 1) { s->scene.skybox = ppmLoader::ImageRGB(); return HRT_OK; }  // no skybox: dark_sky decides
+    s->scene.skybox = to_image(w, h, rgb);
+    return HRT_OK;
+}
+
 int hrt_host_scene_add_sphere(hrt_host_scene *s, const float c[3], float radius, const hrt_material *m) {
     if (!s || !c) return fail(HRT_ERR_INVALID, "add_sphere: NULL argument");
     s->scene.spheres.emplace_back(Vec3(c[0], c[1], c[2]), radius);

@@ -37,6 +37,9 @@ int hrt_host_scene_setup(hrt_host_scene *s, const char *name, float aspect_ratio
 int hrt_host_scene_clear(hrt_host_scene *s);
 int hrt_host_scene_add_texture(hrt_host_scene *s, int32_t w, int32_t h, const uint8_t *rgb);
 int hrt_host_scene_add_normal_map(hrt_host_scene *s, int32_t w, int32_t h, const uint8_t *rgb);
+/* Scene::loadSkybox from memory (Scene.h:163-165): an equirectangular RGB8 image looked up by ray direction
+ * (Scene::skyboxTexture, Scene.h:149-161); rgb == NULL removes it. */
+int hrt_host_scene_set_skybox(hrt_host_scene *s, int32_t w, int32_t h, const uint8_t *rgb);
 int hrt_host_scene_add_sphere(hrt_host_scene *s, const float center[3], float radius,
                               const hrt_material *material);
 /* Square::setQuad(bottomLeft, rightVector, upVector, width, height) */
