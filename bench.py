@@ -172,7 +172,9 @@ def main():
             "kernel_ms_per_launch": round(avg_kernel_s * 1e3, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_sample": round(bps, 1)},
+                         "algorithmic_bytes_per_sample": round(bps, 1),
+                         "note": "achieved = SURVEY 8(d) algorithmic bytes / kernel time; those records are served from SGPRs, LDS "
+                                 "and L2, so frac can exceed 1; traffic = L2<->fabric bytes per launch from rocprofv3 PMC (path records)"},
         }
         if frame is not None:
             out["frame_mean"] = round(float(frame.mean().item()), 6)
