@@ -43,6 +43,9 @@
 #ifndef HRT_SP_WG
 #define HRT_SP_WG 1024     // threads per workgroup (16 waves = 4 per SIMD, one workgroup per CU)
 #endif
+#ifndef HRT_SP_MINW
+#define HRT_SP_MINW 4      // waves per SIMD the register allocator leaves room for (A/B builds: 5 with two 640-thread workgroups per CU)
+#endif
 #define HRT_SP_SCHUNK 1024 // most samples per pixel traced between two ordered folds
 #ifndef HRT_SP_UNIT
 #define HRT_SP_UNIT 32768  // paths of one work unit = tiles of the group x 64 pixels x samples per fold (scratch: 12 B each)
@@ -455,5 +458,5 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 
 }  // namespace hrtk
 
-extern "C" __global__ void __launch_bounds__(HRT_SP_WG, 4) hrt_wgstream_kernel(const DRender R) { hrtk::stream_body<false>(R); }
-extern "C" __global__ void __launch_bounds__(HRT_SP_WG, 4) hrt_wgstream_kernel_lights(const DRender R) { hrtk::stream_body<true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel(const DRender R) { hrtk::stream_body<false>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_lights(const DRender R) { hrtk::stream_body<true>(R); }
