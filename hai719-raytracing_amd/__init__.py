@@ -28,6 +28,8 @@ FLAG_WAVE_KERNEL = 4
 FLAG_STREAM_KERNEL = 8
 FLAG_NO_SHADOW_CULL = 16
 FLAG_DUAL_KERNEL = 32
+FLAG_EXACT_ONLY = 64   # proof builds: no filters, no reciprocal approximations (include/hrt.h)
+FLAG_MESH_BRUTE = 128  # with FLAG_EXACT_ONLY: every triangle of a gated mesh, no KD walk
 
 MAT_DIFFUSE, MAT_GLASS, MAT_MIRROR = 0, 1, 2
 TEX_NONE, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
@@ -159,6 +161,7 @@ def device_lib() -> C.CDLL:
         lib.hrt_finalize_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.hrt_encode_ppm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t), C.c_void_p]
+        lib.hrt_debug_kat.argtypes = [C.c_uint32, C.POINTER(Camera), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _dev = lib
     return _dev
 
@@ -327,6 +330,24 @@ class DeviceScene:
         ms = C.c_double()
         self._check(self._lib.hrt_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+KAT_CAMERA, KAT_TRIANGLE, KAT_AABB, KAT_SPHERE, KAT_QUAD, KAT_OPTICS, KAT_NORMALIZE = range(7)
+_KAT_IN = {KAT_CAMERA: 2, KAT_TRIANGLE: 7, KAT_AABB: 7, KAT_SPHERE: 7, KAT_QUAD: 7, KAT_OPTICS: 8, KAT_NORMALIZE: 3}
+_KAT_OUT = {KAT_CAMERA: 12, KAT_TRIANGLE: 8, KAT_AABB: 2, KAT_SPHERE: 9, KAT_QUAD: 8, KAT_OPTICS: 8, KAT_NORMALIZE: 3}
+
+
+def debug_kat(which: int, inp, prim=None, cam: Optional[Camera] = None) -> np.ndarray:
+    """hrt_debug_kat: the DEVICE functions of the trace path on caller vectors (include/hrt.h); returns (n, out width)."""
+    lib = device_lib()
+    a = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1, _KAT_IN[which])
+    out = np.empty((a.shape[0], _KAT_OUT[which]), dtype=np.float32)
+    pr = None if prim is None else np.ascontiguousarray(prim, dtype=np.float32)
+    rc = lib.hrt_debug_kat(which, None if cam is None else C.byref(cam), None if pr is None else pr.ctypes.data, a.ctypes.data,
+                           a.shape[0], out.ctypes.data)
+    if rc < 0:
+        raise HrtError(f"hrt_debug_kat failed ({rc}): {lib.hrt_last_error().decode()}")
+    return out
 
 
 def tiles_total(w: int, h: int) -> int:

@@ -5,6 +5,7 @@
 #include "hrt_dual.hip"
 #include "hrt_stream.hip"
 #include "hrt_output.hip"
+#include "hrt_kat.hip"
 
 #include <chrono>
 #include <cmath>
@@ -64,10 +65,90 @@ double h_mul64(double a, double b) {
 #pragma clang fp contract(off)
     return a * b;
 }
+double h_neg_dot3(const double r[3], const float e[3]) {  // -(r . e), left to right, no contraction (as oracle/oracle.cpp builds it)
+#pragma clang fp contract(off)
+    return -(r[0] * (double)e[0] + r[1] * (double)e[1] + r[2] * (double)e[2]);
+}
+// gluInvertMatrix (matrixUtilities.h:77-206): adjugate over determinant.  Each adjugate entry is six signed triple
+// products ((s*m[a]) * m[b]) * m[c] summed in the order listed, which is the order the reference writes them in, so
+// every entry rounds as the reference's.
+static const signed char k_adjugate[16][6][4] = {
+    {{1, 5, 10, 15}, {-1, 5, 11, 14}, {-1, 9, 6, 15}, {1, 9, 7, 14}, {1, 13, 6, 11}, {-1, 13, 7, 10}},
+    {{-1, 1, 10, 15}, {1, 1, 11, 14}, {1, 9, 2, 15}, {-1, 9, 3, 14}, {-1, 13, 2, 11}, {1, 13, 3, 10}},
+    {{1, 1, 6, 15}, {-1, 1, 7, 14}, {-1, 5, 2, 15}, {1, 5, 3, 14}, {1, 13, 2, 7}, {-1, 13, 3, 6}},
+    {{-1, 1, 6, 11}, {1, 1, 7, 10}, {1, 5, 2, 11}, {-1, 5, 3, 10}, {-1, 9, 2, 7}, {1, 9, 3, 6}},
+    {{-1, 4, 10, 15}, {1, 4, 11, 14}, {1, 8, 6, 15}, {-1, 8, 7, 14}, {-1, 12, 6, 11}, {1, 12, 7, 10}},
+    {{1, 0, 10, 15}, {-1, 0, 11, 14}, {-1, 8, 2, 15}, {1, 8, 3, 14}, {1, 12, 2, 11}, {-1, 12, 3, 10}},
+    {{-1, 0, 6, 15}, {1, 0, 7, 14}, {1, 4, 2, 15}, {-1, 4, 3, 14}, {-1, 12, 2, 7}, {1, 12, 3, 6}},
+    {{1, 0, 6, 11}, {-1, 0, 7, 10}, {-1, 4, 2, 11}, {1, 4, 3, 10}, {1, 8, 2, 7}, {-1, 8, 3, 6}},
+    {{1, 4, 9, 15}, {-1, 4, 11, 13}, {-1, 8, 5, 15}, {1, 8, 7, 13}, {1, 12, 5, 11}, {-1, 12, 7, 9}},
+    {{-1, 0, 9, 15}, {1, 0, 11, 13}, {1, 8, 1, 15}, {-1, 8, 3, 13}, {-1, 12, 1, 11}, {1, 12, 3, 9}},
+    {{1, 0, 5, 15}, {-1, 0, 7, 13}, {-1, 4, 1, 15}, {1, 4, 3, 13}, {1, 12, 1, 7}, {-1, 12, 3, 5}},
+    {{-1, 0, 5, 11}, {1, 0, 7, 9}, {1, 4, 1, 11}, {-1, 4, 3, 9}, {-1, 8, 1, 7}, {1, 8, 3, 5}},
+    {{-1, 4, 9, 14}, {1, 4, 10, 13}, {1, 8, 5, 14}, {-1, 8, 6, 13}, {-1, 12, 5, 10}, {1, 12, 6, 9}},
+    {{1, 0, 9, 14}, {-1, 0, 10, 13}, {-1, 8, 1, 14}, {1, 8, 2, 13}, {1, 12, 1, 10}, {-1, 12, 2, 9}},
+    {{-1, 0, 5, 14}, {1, 0, 6, 13}, {1, 4, 1, 14}, {-1, 4, 2, 13}, {-1, 12, 1, 6}, {1, 12, 2, 5}},
+    {{1, 0, 5, 10}, {-1, 0, 6, 9}, {-1, 4, 1, 10}, {1, 4, 2, 9}, {1, 8, 1, 6}, {-1, 8, 2, 5}}};
+bool host_invert4(const double m[16], double out[16]) {
+#pragma clang fp contract(off)
+    double adj[16];
+    for (int e = 0; e < 16; ++e) {
+        double sum = 0.0;
+        for (int k = 0; k < 6; ++k) {
+            const signed char *t = k_adjugate[e][k];
+            const double term = ((t[0] < 0 ? -m[t[1]] : m[t[1]]) * m[t[2]]) * m[t[3]];
+            sum = k == 0 ? term : sum + term;
+        }
+        adj[e] = sum;
+    }
+    double det = m[0] * adj[0] + m[1] * adj[4] + m[2] * adj[8] + m[3] * adj[12];
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int e = 0; e < 16; ++e) out[e] = adj[e] * det;
+    return true;
+}
 float h_len(H3 a) { return (float)std::sqrt((double)h_dot(a, a)); }
 H3 h_normalize(H3 a) {
     float L = h_len(a);
     return H3{a.x / L, a.y / L, a.z / L};
+}
+
+// Square::intersect's per-call constants (Square.h:66-72: edges, normal, |R|, |U|, D0), computed once in the same fp32
+// arithmetic -> the 11 float4 rows of hrt_device.h.
+void fold_quad(const hrt_quad &q, const hrt_material &m, std::vector<float4> &quads) {
+    const H3 v0{q.v0[0], q.v0[1], q.v0[2]}, v1{q.v1[0], q.v1[1], q.v1[2]}, v3{q.v3[0], q.v3[1], q.v3[2]};
+    const H3 R = h_sub(v1, v0), U = h_sub(v3, v0);
+    const H3 n = h_normalize(h_cross(R, U));
+    uint32_t flags = 0;
+    if (m.type == HRT_MAT_GLASS) flags |= HRT_QUAD_FLAG_GLASS;
+    if (m.motion[0] != 0.f || m.motion[1] != 0.f || m.motion[2] != 0.f) flags |= HRT_QUAD_FLAG_MOVING;
+    quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
+    quads.push_back(make_float4(n.x, n.y, n.z, as_float(flags)));
+    quads.push_back(make_float4(R.x, R.y, R.z, h_len(R)));
+    quads.push_back(make_float4(U.x, U.y, U.z, h_len(U)));
+    quads.push_back(make_float4(m.motion[0], m.motion[1], m.motion[2], as_float((uint32_t)q.material)));
+    quads.push_back(make_float4(q.tangent[0], q.tangent[1], q.tangent[2], 0.f));
+    quads.push_back(make_float4(q.bitangent[0], q.bitangent[1], q.bitangent[2], 0.f));
+    // the filter's copy (hrt_device.h): values identical to the rows above, only their order differs
+    quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
+    quads.push_back(make_float4(n.y, n.z, n.x, as_float(flags)));
+    quads.push_back(make_float4(R.x, U.x, R.y, U.y));
+    quads.push_back(make_float4(R.z, U.z, h_len(R), h_len(U)));
+}
+
+// Triangle(c0,c1,c2) + computeBarycentricCoordinates constants (Triangle.h:26-37, 62-70) -> the 5 rows of hrt_device.h.
+void fold_triangle(const H3 c[3], uint32_t id, std::vector<float4> &tris) {
+    const H3 e1 = h_sub(c[1], c[0]), e2 = h_sub(c[2], c[0]);
+    const H3 nn = h_cross(e1, e2);
+    const float norm = h_len(nn);
+    const H3 n{nn.x / norm, nn.y / norm, nn.z / norm};
+    const float d00 = h_dot(e1, e1), d01 = h_dot(e1, e2), d11 = h_dot(e2, e2);
+    const float denom = h_msub(d00, d11, d01, d01);
+    tris.push_back(make_float4(c[0].x, c[0].y, c[0].z, as_float(id)));
+    tris.push_back(make_float4(e1.x, e1.y, e1.z, d00));
+    tris.push_back(make_float4(e2.x, e2.y, e2.z, d01));
+    tris.push_back(make_float4(n.x, n.y, n.z, h_dot(c[0], n)));
+    tris.push_back(make_float4(d11, denom, 0.f, 0.f));
 }
 
 template <class T>
@@ -137,6 +218,9 @@ int hrt_init(int device_ordinal) {
                                     (int)g_rt.lds_budget));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g_rt.lds_budget));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_rt.lds_budget));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace_kernel_lights_exact, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)g_rt.lds_budget));
     }
     if (HRT_WG > 256) {  // one big workgroup per CU: backed-up streams + nodelets go past the 64 KiB default
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_trace2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -151,6 +235,8 @@ int hrt_init(int device_ordinal) {
         const int max_lds = 160 * 1024;
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_exact, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights_exact, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const char *k = std::getenv("HRT_KERNEL");
         const std::string ks = k ? k : "";
         g_rt.use_dual = ks != "single";
@@ -237,24 +323,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     for (uint32_t i = 0; i < D.n_quads; ++i) {
         const hrt_quad &q = D.quads[i];
         const hrt_material &m = D.materials[q.material];
-        const H3 v0{q.v0[0], q.v0[1], q.v0[2]}, v1{q.v1[0], q.v1[1], q.v1[2]}, v3{q.v3[0], q.v3[1], q.v3[2]};
-        const H3 R = h_sub(v1, v0), U = h_sub(v3, v0);
-        const H3 n = h_normalize(h_cross(R, U));
-        uint32_t flags = 0;
-        if (m.type == HRT_MAT_GLASS) flags |= HRT_QUAD_FLAG_GLASS;
-        if (m.motion[0] != 0.f || m.motion[1] != 0.f || m.motion[2] != 0.f) flags |= HRT_QUAD_FLAG_MOVING;
-        quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
-        quads.push_back(make_float4(n.x, n.y, n.z, as_float(flags)));
-        quads.push_back(make_float4(R.x, R.y, R.z, h_len(R)));
-        quads.push_back(make_float4(U.x, U.y, U.z, h_len(U)));
-        quads.push_back(make_float4(m.motion[0], m.motion[1], m.motion[2], as_float((uint32_t)q.material)));
-        quads.push_back(make_float4(q.tangent[0], q.tangent[1], q.tangent[2], 0.f));
-        quads.push_back(make_float4(q.bitangent[0], q.bitangent[1], q.bitangent[2], 0.f));
-        // the filter's copy (hrt_device.h): values identical to the rows above, only their order differs
-        quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
-        quads.push_back(make_float4(n.y, n.z, n.x, as_float(flags)));
-        quads.push_back(make_float4(R.x, U.x, R.y, U.y));
-        quads.push_back(make_float4(R.z, U.z, h_len(R), h_len(U)));
+        fold_quad(q, m, quads);
     }
     for (uint32_t i = 0; i < D.n_lights; ++i) {
         const hrt_light &l = D.lights[i];
@@ -365,20 +434,10 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 const float *p = M.positions + 3 * (size_t)M.indices[3 * (size_t)t + j];
                 c[j] = H3{p[0] * HRT_TRIANGLE_SCALING, p[1] * HRT_TRIANGLE_SCALING, p[2] * HRT_TRIANGLE_SCALING};
             }
-            // Triangle(c0,c1,c2) + computeBarycentricCoordinates constants (Triangle.h:26-37, 62-70)
-            const H3 e1 = h_sub(c[1], c[0]), e2 = h_sub(c[2], c[0]);
-            const H3 nn = h_cross(e1, e2);
-            const float norm = h_len(nn);
-            const H3 n{nn.x / norm, nn.y / norm, nn.z / norm};
-            const float d00 = h_dot(e1, e1), d01 = h_dot(e1, e2), d11 = h_dot(e2, e2);
-            const float denom = h_msub(d00, d11, d01, d01);
-            tris.push_back(make_float4(c[0].x, c[0].y, c[0].z, as_float(t)));
-            tris.push_back(make_float4(e1.x, e1.y, e1.z, d00));
-            tris.push_back(make_float4(e2.x, e2.y, e2.z, d01));
-            tris.push_back(make_float4(n.x, n.y, n.z, h_dot(c[0], n)));
-            tris.push_back(make_float4(d11, denom, 0.f, 0.f));
+            fold_triangle(c, t, tris);
         }
         dm.tri_base = tri_base;
+        dm.n_soup = M.n_leaf_tris;
         dm.material = (uint32_t)M.material;
         dm.color_type = HRT_COLOR_NONE;
         if (M.color_type == HRT_COLOR_FACE && M.face_colors) {
@@ -467,6 +526,61 @@ uint32_t hrt_tiles_owned(uint32_t w, uint32_t h, uint32_t rank, uint32_t world) 
     return (t - rank + world - 1) / world;
 }
 
+// hrt_camera -> the constants camera_ray() reads (hrt_device.h DCamera).
+static int make_camera(const hrt_camera *cam, DCamera &C) {
+    std::memset(&C, 0, sizeof(C));
+    // The GL matrices the reference reads back (matrixUtilities.h:33-46) for this pose, fp64, column-major:
+    // modelview = [right; up; -forward] * translate(-eye) (Camera.cpp:125-132), projection = gluPerspective(fovy,
+    // aspect, znear, zfar) (Camera.cpp:41-50) -- then inverted by the reference's own method, the adjugate over the
+    // determinant term by term (matrixUtilities.h:77-206; host_invert4 above), so that every constant below carries
+    // the reference's rounding.  hrt_debug_kat(HRT_KAT_CAMERA) exposes the resulting rays; tests compare them bit for
+    // bit with rays produced by the reference's gluInvertMatrix + screen_space_to_world_space_ray.
+    {
+        double mv[16], pr[16], mi[16], pi[16];
+        for (int k = 0; k < 16; ++k) { mv[k] = 0.0; pr[k] = 0.0; }
+        const double Rm[3][3] = {{cam->right[0], cam->right[1], cam->right[2]},
+                                 {cam->up[0], cam->up[1], cam->up[2]},
+                                 {-(double)cam->forward[0], -(double)cam->forward[1], -(double)cam->forward[2]}};
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) mv[k * 4 + r] = Rm[r][k];
+            mv[12 + r] = h_neg_dot3(Rm[r], cam->eye);
+        }
+        mv[15] = 1.0;
+        const double rad = (double)cam->fovy_deg / 2.0 * M_PI / 180.0;
+        const double cot = std::cos(rad) / std::sin(rad);
+        const double dz = (double)cam->zfar - (double)cam->znear;
+        pr[0] = cot / (double)cam->aspect;
+        pr[5] = cot;
+        pr[10] = -((double)cam->zfar + (double)cam->znear) / dz;
+        pr[11] = -1.0;
+        pr[14] = h_mul64(h_mul64(-2.0, (double)cam->znear), (double)cam->zfar) / dz;
+        if (!host_invert4(mv, mi) || !host_invert4(pr, pi)) return fail(HRT_ERR_INVALID, "render: singular camera matrix");
+        // The kernel evaluates the two mat-vecs of matrixUtilities.h:60-68 with their structural zeros removed, which is
+        // exact only for this sparsity (a zero coefficient contributes a signed zero, and x + (+-0) == x):
+        //   P^-1 = [pi0 . . .; . pi5 . .; . . . pi14; . . pi11 pi15]      MV^-1 = [* * * *; * * * *; * * * *; 0 0 0 m15]
+        static const int p_zero[] = {1, 2, 3, 4, 6, 7, 8, 9, 10, 12, 13}, m_zero[] = {3, 7, 11};
+        for (int k : p_zero) if (pi[k] != 0.0) return fail(HRT_ERR_INVALID, "render: projection inverse is not of the gluPerspective form");
+        for (int k : m_zero) if (mi[k] != 0.0) return fail(HRT_ERR_INVALID, "render: modelview inverse is not affine");
+        bool finite = true;
+        for (int k = 0; k < 16; ++k) finite = finite && std::isfinite(mi[k]) && std::isfinite(pi[k]);
+        if (!finite) return fail(HRT_ERR_INVALID, "render: camera is not finite");
+        // resInt = P^-1 (x, y, 0, 1):  resInt0 = pi0*x, resInt1 = pi5*y, resInt2 = pi14, resInt3 = pi15   (z = GL_DEPTH_RANGE[0] = 0)
+        // res_k  = ((m[k]*resInt0 + m[4+k]*resInt1) + m[8+k]*resInt2) + m[12+k]*resInt3,   res_3 = m[15]*resInt3
+        const double ri2 = pi[14], ri3 = pi[15];
+        for (int a = 0; a < 3; ++a) C.eye[a] = (float)(mi[12 + a] / mi[15]);  // cameraSpaceToWorldSpace(0,0,0), :53-58
+        C.pi0 = pi[0]; C.pi5 = pi[5];
+        C.pi15 = h_mul64(mi[15], ri3);   // res_3, the divisor of :66-68
+        C.inv15 = 1.0 / C.pi15;
+        for (int k = 0; k < 3; ++k) {
+            C.mx[k] = mi[k];
+            C.my[k] = mi[4 + k];
+            C.c1[k] = h_mul64(mi[8 + k], ri2);
+            C.c2[k] = h_mul64(mi[12 + k], ri3);
+        }
+    }
+    return HRT_OK;
+}
+
 static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
                        uint32_t flags, uint32_t rank, uint32_t world, DRender &R, hipStream_t stream) {
     if (!s || !cam) return fail(HRT_ERR_INVALID, "render: NULL argument");
@@ -479,34 +593,9 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
     R.lds_units = (flags & HRT_FLAG_NO_LDS_TREE) ? 0u : s->lds_units;
     R.err_abs = 2e-6f * (s->bound + std::sqrt(cam->eye[0] * cam->eye[0] + cam->eye[1] * cam->eye[1] + cam->eye[2] * cam->eye[2]) + 1.f);
     DCamera C;
-    std::memset(&C, 0, sizeof(C));
-    // Inverse modelview / projection of the GL camera the reference reads back (matrixUtilities.h:33-50),
-    // in closed form, fp64, column-major: modelview = [right; up; -forward] * translate(-eye),
-    // projection = gluPerspective(fovy, aspect, znear, zfar) (Camera.cpp:41-50).
     {
-        double mi[16], pi[16];
-        for (int k = 0; k < 16; ++k) { mi[k] = 0.0; pi[k] = 0.0; }
-        for (int r = 0; r < 3; ++r) {
-            mi[0 + r] = (double)cam->right[r];
-            mi[4 + r] = (double)cam->up[r];
-            mi[8 + r] = -(double)cam->forward[r];
-            mi[12 + r] = (double)cam->eye[r];
-        }
-        mi[15] = 1.0;
-        const double rad = (double)cam->fovy_deg / 2.0 * M_PI / 180.0;
-        const double cot = std::cos(rad) / std::sin(rad);
-        const double dz = (double)cam->zfar - (double)cam->znear;
-        const double pa = cot / (double)cam->aspect, pb = cot;
-        const double pc = -((double)cam->zfar + (double)cam->znear) / dz, pd = -2.0 * (double)cam->znear * (double)cam->zfar / dz;
-        pi[0] = 1.0 / pa; pi[5] = 1.0 / pb; pi[11] = 1.0 / pd; pi[14] = -1.0; pi[15] = pc / pd;
-        for (int a = 0; a < 3; ++a) C.eye[a] = (float)(mi[12 + a] / mi[15]);
-        C.pi0 = pi[0]; C.pi5 = pi[5]; C.pi15 = pi[15]; C.inv15 = 1.0 / pi[15];
-        for (int k = 0; k < 3; ++k) {
-            C.mx[k] = mi[k];
-            C.my[k] = mi[4 + k];
-            C.c1[k] = mi[8 + k] * -1.0;
-            C.c2[k] = h_mul64(mi[12 + k], pi[15]);
-        }
+        const int crc = make_camera(cam, C);
+        if (crc != HRT_OK) return crc;
     }
     if (!s->cam_valid || std::memcmp(&C, &s->h_cam, sizeof(C)) != 0) {
         // the previous launch may still be reading the old block: stream order makes the copy wait for it
@@ -548,8 +637,11 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     const bool stream_pays = s->d.n_meshes > 0u || s->d.n_lights > 0u;
     const bool stream_kernel = !(flags & (HRT_FLAG_WAVE_KERNEL | HRT_FLAG_DUAL_KERNEL)) &&
                                (g_rt.use_stream == 1 || (flags & HRT_FLAG_STREAM_KERNEL) || (g_rt.use_stream < 0 && stream_pays));
-    const bool dual_kernel = !stream_kernel && (g_rt.use_dual || (flags & HRT_FLAG_DUAL_KERNEL)) && s->d.n_meshes > 0u && s->max_leaf < 0xFFFFu &&
-                             !(flags & HRT_FLAG_WAVE_KERNEL);
+    const bool exact = (flags & HRT_FLAG_EXACT_ONLY) != 0u;  // proof builds exist for the lane-per-pixel and streaming forms
+    if ((flags & HRT_FLAG_MESH_BRUTE) && !exact) return fail(HRT_ERR_INVALID, "render: HRT_FLAG_MESH_BRUTE needs HRT_FLAG_EXACT_ONLY");
+    if (exact && (flags & HRT_FLAG_DUAL_KERNEL)) return fail(HRT_ERR_INVALID, "render: no exact-only build of the two-stream kernel");
+    const bool dual_kernel = !exact && !stream_kernel && (g_rt.use_dual || (flags & HRT_FLAG_DUAL_KERNEL)) && s->d.n_meshes > 0u &&
+                             s->max_leaf < 0xFFFFu && !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
         const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4);
@@ -584,7 +676,8 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
         }
         R.sp_pool = s->sp_pool;
     } else {
-        const void *kfn = s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel;
+        const void *kfn = exact ? (s->d.n_lights ? (const void *)hrt_trace_kernel_lights_exact : (const void *)hrt_trace_kernel_exact)
+                                : (s->d.n_lights ? (const void *)hrt_trace_kernel_lights : (const void *)hrt_trace_kernel);
         lds_bytes = R.lds_units * 16u;
         if (dual_kernel) {
             // 4 workgroups per CU: 160 KiB = 4 x (27 KiB of backed-up streams + 12 KiB of nodelets)
@@ -611,9 +704,15 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     HIP_TRY(hipMemsetAsync(s->tile_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(s->stamps, 0, 16 * sizeof(unsigned long long), stream));  // [15] = give-up code of the streaming kernel
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (stream_kernel) {
+    if (stream_kernel && exact) {
+        if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights_exact, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+        else hipLaunchKernelGGL(hrt_wgstream_kernel_exact, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+    } else if (stream_kernel) {
         if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
         else hipLaunchKernelGGL(hrt_wgstream_kernel, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+    } else if (exact) {
+        if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace_kernel_lights_exact, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
+        else hipLaunchKernelGGL(hrt_trace_kernel_exact, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
     } else {
         if (dual_kernel) {
             if (s->d.n_lights) hipLaunchKernelGGL(hrt_trace2_kernel_lights, dim3(grid), dim3(HRT_WG), lds_bytes, stream, R);
@@ -819,6 +918,74 @@ int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32
     if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(HRT_ERR_DEVICE, std::string("hrt_debug_path_stream: ") + hipGetErrorString(e));
+    return HRT_OK;
+}
+
+// Known-answer instrument: device functions on caller vectors (include/hrt.h).
+int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, const float *in, uint32_t n, float *out) {
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_debug_kat: call hrt_init first");
+    if (!in || !out || !n) return fail(HRT_ERR_INVALID, "hrt_debug_kat: bad argument");
+    static const uint32_t in_w[] = {2, 7, 7, 7, 7, 8, 3}, out_w[] = {12, 8, 2, 9, 8, 8, 3};
+    if (which > HRT_KAT_NORMALIZE) return fail(HRT_ERR_INVALID, "hrt_debug_kat: unknown instrument");
+    if ((which == HRT_KAT_CAMERA) != (cam != nullptr) || ((which >= HRT_KAT_TRIANGLE && which <= HRT_KAT_QUAD) != (prim != nullptr)))
+        return fail(HRT_ERR_INVALID, "hrt_debug_kat: cam is for HRT_KAT_CAMERA, prim for the primitive instruments");
+    std::vector<float4> rows;
+    std::vector<float> box;
+    float err_abs = 0.f;
+    DCamera C;
+    if (which == HRT_KAT_CAMERA) {
+        const int rc = make_camera(cam, C);
+        if (rc != HRT_OK) return rc;
+    } else if (which == HRT_KAT_TRIANGLE) {  // prim: c0, c1, c2 as handed to the Triangle constructor
+        const H3 c[3] = {{prim[0], prim[1], prim[2]}, {prim[3], prim[4], prim[5]}, {prim[6], prim[7], prim[8]}};
+        fold_triangle(c, 0u, rows);
+    } else if (which == HRT_KAT_AABB) {
+        box.assign(prim, prim + 6);
+    } else if (which == HRT_KAT_SPHERE) {    // prim: centre, radius, motion
+        rows.push_back(make_float4(prim[0], prim[1], prim[2], prim[3]));
+        rows.push_back(make_float4(prim[4], prim[5], prim[6], as_float(0u)));
+    } else if (which == HRT_KAT_QUAD) {      // prim: v0, v1, v3, motion, glass flag
+        hrt_quad q;
+        std::memset(&q, 0, sizeof(q));
+        hrt_material m;
+        std::memset(&m, 0, sizeof(m));
+        for (int k = 0; k < 3; ++k) { q.v0[k] = prim[k]; q.v1[k] = prim[3 + k]; q.v3[k] = prim[6 + k]; m.motion[k] = prim[9 + k]; }
+        m.type = prim[12] != 0.f ? HRT_MAT_GLASS : HRT_MAT_DIFFUSE;
+        fold_quad(q, m, rows);
+        double b = 0.0;
+        for (int k = 0; k < 13; ++k) b = std::max(b, (double)std::fabs(prim[k]));
+        for (size_t k = 0; k < (size_t)n * 7; ++k) if (k % 7 < 3) b = std::max(b, (double)std::fabs(in[k]));
+        err_abs = 2e-6f * ((float)(b * 4.0) + 1.f);  // the margin scale fill_render derives from the scene extent
+    }
+    void *d_prim = nullptr;
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipSuccess;
+    const size_t in_bytes = (size_t)n * in_w[which] * sizeof(float), out_bytes = (size_t)n * out_w[which] * sizeof(float);
+    const void *h_prim = which == HRT_KAT_CAMERA ? (const void *)&C : (which == HRT_KAT_AABB ? (const void *)box.data() : (const void *)rows.data());
+    const size_t prim_bytes = which == HRT_KAT_CAMERA ? sizeof(C) : (which == HRT_KAT_AABB ? 6 * sizeof(float) : rows.size() * sizeof(float4));
+    if (prim_bytes) e = hipMalloc(&d_prim, prim_bytes);
+    if (e == hipSuccess && prim_bytes) e = hipMemcpy(d_prim, h_prim, prim_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_in, in_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_bytes);
+    if (e == hipSuccess) {
+        const dim3 grid((n + 255u) / 256u), block(256);
+        switch (which) {
+            case HRT_KAT_CAMERA: hipLaunchKernelGGL(hrt_kat_camera_kernel, grid, block, 0, 0, (const DCamera *)d_prim, d_in, n, d_out); break;
+            case HRT_KAT_TRIANGLE: hipLaunchKernelGGL(hrt_kat_triangle_kernel, grid, block, 0, 0, (const float4 *)d_prim, d_in, n, d_out); break;
+            case HRT_KAT_AABB: hipLaunchKernelGGL(hrt_kat_aabb_kernel, grid, block, 0, 0, (const float *)d_prim, d_in, n, d_out); break;
+            case HRT_KAT_SPHERE: hipLaunchKernelGGL(hrt_kat_sphere_kernel, grid, block, 0, 0, (const float4 *)d_prim, d_in, n, d_out); break;
+            case HRT_KAT_QUAD: hipLaunchKernelGGL(hrt_kat_quad_kernel, grid, block, 0, 0, (const float4 *)d_prim, d_in, n, err_abs, d_out); break;
+            case HRT_KAT_OPTICS: hipLaunchKernelGGL(hrt_kat_optics_kernel, grid, block, 0, 0, d_in, n, d_out); break;
+            default: hipLaunchKernelGGL(hrt_kat_normalize_kernel, grid, block, 0, 0, d_in, n, d_out); break;
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    if (d_prim) (void)hipFree(d_prim);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(HRT_ERR_DEVICE, std::string("hrt_debug_kat: ") + hipGetErrorString(e));
     return HRT_OK;
 }
 

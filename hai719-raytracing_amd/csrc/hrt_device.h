@@ -42,7 +42,8 @@ struct DMesh {
     int32_t color_type;
     uint32_t color_base;           // into colours (face) or into vert ids / vertex colours
     uint32_t vcolor_base;
-    uint32_t pad0, pad1;
+    uint32_t n_soup;               // rows-of-five in this mesh's leaf-ordered soup (straddlers repeated)
+    uint32_t pad1;
 };
 
 struct DImage {
@@ -69,15 +70,17 @@ struct DScene {
 };
 
 struct DCamera {
-    // The two fp64 mat-vecs of matrixUtilities.h:60-68 with their structural zeros removed.  With
-    // P^-1 = [pi0 . . .; . pi5 . .; . . . -1; . . pi11 pi15] (column-major p_inv[0,5,11,14,15]) and
-    // MV^-1 = [right up -forward eye; 0 0 0 1], the reference's left-to-right sums reduce EXACTLY to
-    //   ri = (pi0*x, pi5*y, -1, pi15)      r_k = ((mx[k]*ri0 + my[k]*ri1) + c1[k]) + c2[k]      r_3 = pi15
-    // because adding (+-)0 and multiplying by -1 or 1 round nothing.
-    double pi0, pi5, pi15, inv15;  // inv15 = 1/pi15 (fast path of the division, see camera_ray)
+    // The two fp64 mat-vecs of matrixUtilities.h:60-68 with their structural zeros removed.  The host inverts the GL
+    // matrices with the reference's own method (hrt_api.hip host_invert4 == gluInvertMatrix, term by term) and checks
+    // the sparsity  P^-1 = [pi0 . . .; . pi5 . .; . . . pi14; . . pi11 pi15],  MV^-1 = [* * * *; * * * *; * * * *; 0 0 0 m15].
+    // With z = GL_DEPTH_RANGE[0] = 0 the reference's left-to-right sums then reduce EXACTLY (a zero coefficient adds a
+    // signed zero, and x + (+-0) == x) to
+    //   ri = (pi0*x, pi5*y, pi14, pi15)      r_k = ((mx[k]*ri0 + my[k]*ri1) + c1[k]) + c2[k]      r_3 = fl(m15*pi15)
+    double pi0, pi5;
+    double pi15, inv15;            // r_3, the divisor of matrixUtilities.h:66-68, and 1/r_3 (fast path of the division, see camera_ray)
     double mx[3], my[3];           // MV^-1 columns 0 and 1
-    double c1[3];                  // MV^-1 column 2 times ri2 = -1           (exact)
-    double c2[3];                  // fl64(MV^-1 column 3 * pi15)             (one rounding, as the reference)
+    double c1[3];                  // fl(MV^-1 column 2 * pi14)   (one rounding each, as the reference)
+    double c2[3];                  // fl(MV^-1 column 3 * pi15)
     float eye[3];                  // cameraSpaceToWorldSpace(0,0,0), matrixUtilities.h:53-58
     float pad;
 };

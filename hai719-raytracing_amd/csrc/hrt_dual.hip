@@ -32,9 +32,6 @@
 #ifndef HRT_WALK_LEVELS
 #define HRT_WALK_LEVELS 3  // inner nodes descended per trip (A/B on MI355X, Cornell+mesh / mesh_in_box: 1 -> 48.3 / 59.8 ms, 2 -> 44.2 / 54.6, 3 -> 43.5 / 53.0, 4 -> 43.6 / 52.7)
 #endif
-#ifndef HRT_WALK_SPEC
-#define HRT_WALK_SPEC 0    // 1: request all five rows of a triangle at once (one latency, more loads)
-#endif
 #ifndef HRT_WALK_ROPES
 #define HRT_WALK_ROPES 0   // 1: request the rope nodelets together with the leaf header
 #endif
@@ -126,8 +123,8 @@ __device__ __forceinline__ void ds_fresh(PathState &p, bool live) {
 
 // Up to `trips` trips of the walk of mesh M (mesh_traverse's loop body, KDTree.cpp:31-85 semantics);
 // true when the walk is complete: w.best_* then hold the mesh's closest triangle with t >= 0, if any.
-template <class MP>  // cmesh: wave-uniform mesh, scalar record loads; gmesh: every lane its own mesh, vector loads
-__device__ __forceinline__ bool mesh_walk(const Ctx &cx, MP M, const Ray &ray, f3 inv, Walk &w, int trips) {
+template <class CX, class MP>  // cmesh: wave-uniform mesh, scalar record loads; gmesh: every lane its own mesh, vector loads
+__device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3 inv, Walk &w, int trips) {
     if (w.ref == HRT_KD_NIL) {  // start: clip the ray to the root cell
         float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
         float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
@@ -167,29 +164,7 @@ __device__ __forceinline__ bool mesh_walk(const Ctx &cx, MP M, const Ray &ray, f
             const uint32_t first = tri_base + l0.w, cnt = l1.w;
             if (k == 0xFFFFu) k = 0;
             if (k < cnt) {
-                gf4 tr = tris + HRT_TRI_ROWS * (first + k);
-                const float4 r3 = ld(tr, 3);
-#if HRT_WALK_SPEC
-                const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
-#endif
-                const f3 n = mk(r3);
-                const float dotRN = dot(ray.d, n);
-                if (dotRN < 0.f) {                                     // Triangle.h:80-91: else parallel / back-facing (NaN: no hit)
-                    const float t = (r3.w - dot(ray.o, n)) / dotRN;    // :95
-                    if (!(t < 0.f) && t < w.best_t) {                  // :96, then the leaf's strict `<` (KDTree.cpp:44)
-#if !HRT_WALK_SPEC
-                        const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
-#endif
-                        const f3 v2 = (ray.o + t * ray.d) - mk(r0);
-                        const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
-                        const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;  // Triangle.h:72-74
-                        const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
-                        const float u0 = 1 - u1 - u2;
-                        if (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1) {
-                            w.best_t = t; w.best_tri = first + k; w.bu = u1; w.bv = u2;
-                        }
-                    }
-                }
+                if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, w.best_t, w.bu, w.bv)) w.best_tri = first + k;
                 ++k;
             }
             if (k >= cnt) {  // leave the cell through its exit face
@@ -225,8 +200,14 @@ __device__ __forceinline__ bool mesh_walk(const Ctx &cx, MP M, const Ray &ray, f
 
 // Up to `trips` trips on each mesh still to be walked, in mesh order (Scene.h:222-228); a finished mesh is merged
 // into the closest hit with the caller's `t >= EPSILON && t < best` and leaves `parked`.  True when none is left.
-__device__ __forceinline__ bool walk_some(const Ctx &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
-    const f3 inv = ray_inv(ray);
+template <class CX>
+__device__ __forceinline__ bool walk_some(const CX &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
+    if (CX::exact && (cx.flags & HRT_FLAG_MESH_BRUTE)) {  // proof build: no tree, every triangle of every gated mesh, at once
+        meshes_hit(cx, ray, parked, h);
+        parked = 0u;
+        return true;
+    }
+    const f3 inv = ray_inv<CX::exact>(ray);
     const uint32_t nm = min(cx.S->n_meshes, 32u);
     for (uint32_t i = 0; i < nm; ++i) {  // wave-uniform loop: scalar mesh records
         if ((parked & (0u - parked)) == (1u << i)) {  // mesh i is this lane's next one
@@ -246,8 +227,10 @@ __device__ __forceinline__ bool walk_some(const Ctx &cx, const Ray &ray, uint32_
 // of a multi-mesh scene walk in the same trips instead of taking turns.  Results cannot differ: a walk depends
 // only on its ray and its mesh.
 typedef const DMesh __attribute__((address_space(1))) *gmesh;
-__device__ __forceinline__ bool walk_some_per_lane(const Ctx &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
-    const f3 inv = ray_inv(ray);
+template <class CX>
+__device__ __forceinline__ bool walk_some_per_lane(const CX &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
+    if (CX::exact && (cx.flags & HRT_FLAG_MESH_BRUTE)) return walk_some(cx, ray, parked, w, h, trips);
+    const f3 inv = ray_inv<CX::exact>(ray);
     gmesh meshes = (gmesh)cx.S->meshes;
     while (parked != 0u) {
         const uint32_t i = (uint32_t)__builtin_ctz(parked);
@@ -262,7 +245,8 @@ __device__ __forceinline__ bool walk_some_per_lane(const Ctx &cx, const Ray &ray
 }
 
 // One stage B visit for a parked stream.
-__device__ __forceinline__ void walk_visit(const Ctx &cx, PathState &p) {
+template <class CX>
+__device__ __forceinline__ void walk_visit(const CX &cx, PathState &p) {
     if (walk_some(cx, p.ray, p.parked, p.w, p.h, HRT_DS_TRIPS)) p.stage = 2u;
 }
 

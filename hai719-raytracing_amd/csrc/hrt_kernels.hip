@@ -150,8 +150,14 @@ struct Hit {
     float a0, a1;    // square: (u,v); mesh: barycentric (w1,w2)
 };
 
-// Everything a device function needs to reach the scene.
-struct Ctx {
+// Everything a device function needs to reach the scene.  EXACT selects, at compile time, the proof build of every
+// kernel form (HRT_FLAG_EXACT_ONLY): no filter and no v_rcp_f32 anywhere in front of the reference arithmetic -- every
+// square goes through quad_t in index order, every mesh gate through aabb_gate_exact, shadow rays test every sphere,
+// the camera quotient and the walk's reciprocals are IEEE divisions.  The shipped (EXACT = false) kernels carry none
+// of that code; tests compare the two bit for bit at full frame size.
+template <bool EXACT>
+struct CtxT {
+    static constexpr bool exact = EXACT;
     cscene S;
     lu4 lds;         // nodelets staged in LDS
     uint32_t lds_n;  // how many
@@ -159,6 +165,7 @@ struct Ctx {
     uint32_t flags;  // HRT_FLAG_* of this launch
     unsigned long long *st;  // diagnostic stamps (HRT_STAMPS builds), else unused
 };
+typedef CtxT<false> Ctx;
 
 // ------------------------------------------------------------------ primitives
 // Sphere.h:91-132; near root only (the far root is unreachable, N6).  2.*x is exact in fp32.
@@ -248,8 +255,9 @@ __device__ __forceinline__ bool aabb_gate_exact(const B &box, const Ray &ray) {
 // KDTree.cpp:82 gate.  An fp32 slab test with a margin settles the clear cases (each slab distance
 // differs from the reference's by <= 3e-7 |t|); only a ray that grazes the box within the margin, or
 // has a zero direction component, pays for the exact fp64 form.
-template <class B>
+template <bool EXACT, class B>
 __device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 inv) {
+    if (EXACT) return aabb_gate_exact(box, ray);
     float g0 = HRT_EPS, g1 = HRT_FLT_MAX, big = 0.f;
     float t0 = (box.lo(0) - ray.o.x) * inv.x, t1 = (box.hi(0) - ray.o.x) * inv.x;
     g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
@@ -267,22 +275,62 @@ __device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 i
     return aabb_gate_exact(box, ray);
 #endif
 }
-__device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) { return mesh_gate_box(MeshBox{M}, ray, inv); }
+template <bool EXACT>
+__device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) { return mesh_gate_box<EXACT>(MeshBox{M}, ray, inv); }
 
 // Nodelet fetch: the leading `lds_n` units of the kd array are resident in LDS.
-__device__ __forceinline__ uint4 kd_fetch(gu4 g, const Ctx &cx, uint32_t i) {
+template <class CX>
+__device__ __forceinline__ uint4 kd_fetch(gu4 g, const CX &cx, uint32_t i) {
     uint4 r;
     if (i < cx.lds_n) r = ld(cx.lds, i);
     else r = ld(g, i);
     return r;
 }
 
+// One triangle of the soup against the ray: Triangle::getIntersection (Triangle.h:77-126) with the constructor's and
+// computeBarycentricCoordinates' constants folded on the host (rows 0 {c0, id} 1 {e1, d00} 2 {e2, d01} 3 {n, D} 4 {d11, denom}),
+// then the leaf's strict `<` against the best so far (KDTree.cpp:44).  True when this triangle became the best.
+__device__ __forceinline__ bool tri_test(gf4 tr, const Ray &ray, float &best_t, float &bu, float &bv) {
+    const float4 r3 = ld(tr, 3);
+    const f3 n = mk(r3);
+    const float dotRN = dot(ray.d, n);
+    if (!(dotRN < 0.f)) return false;                     // :80-91 parallel / back-facing (NaN: no hit)
+    const float t = (r3.w - dot(ray.o, n)) / dotRN;       // :95
+    if (t < 0.f || !(t < best_t)) return false;           // :96, then KDTree.cpp:44
+    const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
+    const f3 v2 = (ray.o + t * ray.d) - mk(r0);
+    const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
+    const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;    // :72-74
+    const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
+    const float u0 = 1 - u1 - u2;
+    if (!(u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1)) return false;
+    best_t = t; bu = u1; bv = u2;
+    return true;
+}
+
+// HRT_FLAG_MESH_BRUTE (exact builds only): every triangle of the mesh's leaf-ordered soup, no tree -- the device-side
+// statement of Mesh::intersectOld (Mesh.h:257-277) with the leaf's strict `<` (KDTree.cpp:44).  A straddling triangle
+// sits in the soup once per leaf: the repeats give an equal t and lose to the first.  Tests compare this with the rope
+// walk at frame scale: the walk only chooses WHICH triangles are tested, so both must select the same closest hit.
+template <class CX>
+__device__ __forceinline__ bool mesh_brute(const CX &cx, cmesh M, const Ray &ray, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
+    gf4 tris = (gf4)cx.S->tris;
+    const uint32_t first = M->tri_base, cnt = M->n_soup;
+    bool found = false;
+    best_t = HRT_FLT_MAX;
+    for (uint32_t k = 0; k < cnt; ++k)
+        if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, best_t, bu, bv)) { best_tri = first + k; found = true; }
+    return found;
+}
+
 // Closest triangle of one mesh with t >= 0 (KDTree.cpp:31-85 semantics: the caller applies
 // `t >= EPSILON && t < best`); the ray has already passed mesh_gate.  Stackless: locate the leaf that
 // holds the entry point, test its triangles, leave through the exit face's rope, repeat while no hit lies
 // inside the visited cells.  Triangle rows: 0 {c0, id} 1 {e1, d00} 2 {e2, d01} 3 {n, D} 4 {d11, denom}.
-__device__ __forceinline__ bool mesh_traverse(const Ctx &cx, cmesh M, const Ray &ray, f3 inv, float &best_t,
+template <class CX>
+__device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &ray, f3 inv, float &best_t,
                                               uint32_t &best_tri, float &bu, float &bv) {
+    if (CX::exact && (cx.flags & HRT_FLAG_MESH_BRUTE)) return mesh_brute(cx, M, ray, best_t, best_tri, bu, bv);
     float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
     {
         float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
@@ -327,24 +375,7 @@ __device__ __forceinline__ bool mesh_traverse(const Ctx &cx, cmesh M, const Ray 
             k = cnt;
 #endif
             if (k < cnt) {
-                gf4 tr = tris + HRT_TRI_ROWS * (first + k);
-                const float4 r3 = ld(tr, 3);
-                const f3 n = mk(r3);
-                const float dotRN = dot(ray.d, n);
-                if (dotRN < 0.f) {                                     // Triangle.h:80-91: else parallel / back-facing (NaN: no hit)
-                    const float t = (r3.w - dot(ray.o, n)) / dotRN;    // :95
-                    if (!(t < 0.f) && t < best_t) {                    // :96, then the leaf's strict `<` (KDTree.cpp:44)
-                        const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
-                        const f3 v2 = (ray.o + t * ray.d) - mk(r0);
-                        const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
-                        const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;  // Triangle.h:72-74
-                        const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
-                        const float u0 = 1 - u1 - u2;
-                        if (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1) {
-                            best_t = t; best_tri = first + k; bu = u1; bv = u2; found = true;
-                        }
-                    }
-                }
+                if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, best_t, bu, bv)) { best_tri = first + k; found = true; }
                 ++k;
             }
             if (k >= cnt) {  // leave the cell through its exit face
@@ -372,15 +403,17 @@ __device__ __forceinline__ bool mesh_traverse(const Ctx &cx, cmesh M, const Ray 
     return found;
 }
 
+template <bool EXACT>
 __device__ __forceinline__ f3 ray_inv(const Ray &ray) {
+    if (EXACT) return mk(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
     return mk(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
 }
 
 // The no-division FILTER over the squares (wave-uniform loop, scalar rows): bit i of the result = square i can possibly
 // be the closest accepted hit (see prims_hit).  M = uint32_t for up to 32 squares (the per-lane mask costs half the VALU
 // work of a 64-bit one), uint64_t for up to 64.
-template <class M>
-__device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, uint32_t nq, float tsure) {
+template <class M, class CX>
+__device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, cf4 qd, uint32_t nq, float tsure) {
     M cand = 0;
     // Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are already in
     // flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
@@ -434,7 +467,8 @@ __device__ __forceinline__ M quad_filter(const Ctx &cx, const Ray &ray, cf4 qd, 
 }
 
 // Spheres then squares of Scene::computeIntersection (Scene.h:207-221).
-__device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
+template <class CX>
+__device__ __forceinline__ Hit prims_hit(const CX &cx, const Ray &ray) {
     cscene S = cx.S;
     Hit h;
     h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
@@ -447,7 +481,7 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
     STAMP(1);
     cf4 qd = (cf4)S->quads;
     const uint32_t nq = S->n_quads;
-    if (nq <= 64u) {
+    if (!CX::exact && nq <= 64u) {
         // FILTER (wave-uniform loop, scalar rows, no division): an approximate t and inside test with
         // conservative error margins decide which quads can possibly be the closest accepted hit.
         // REFINE: only those (usually one per lane) go through the exact Square::intersect arithmetic,
@@ -472,37 +506,40 @@ __device__ __forceinline__ Hit prims_hit(const Ctx &cx, const Ray &ray) {
 }
 
 // Which meshes' boxes the ray enters (bit i = mesh i; the first 32 meshes).
-__device__ __forceinline__ uint32_t mesh_gates(const Ctx &cx, const Ray &ray) {
+template <class CX>
+__device__ __forceinline__ uint32_t mesh_gates(const CX &cx, const Ray &ray) {
     const uint32_t nm = min(cx.S->n_meshes, 32u);
     if (nm == 0) return 0u;
 #ifdef HRT_ABL_NO_GATES  // ablation only (timing experiments, not parity-safe)
     return 0u;
 #endif
-    const f3 inv = ray_inv(ray);
+    const f3 inv = ray_inv<CX::exact>(ray);
     uint32_t m = 0;
     for (uint32_t i = 0; i < nm; ++i)
-        if (mesh_gate((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
+        if (mesh_gate<CX::exact>((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
     return m;
 }
 
 // mesh_gates with the count and the first mesh's box already in registers (loaded once per wave): for the
 // common one-mesh scene no scalar load -- three dependent ones otherwise -- sits between the primitives and
 // the vote of every bounce.
-__device__ __forceinline__ uint32_t mesh_gates_pre(const Ctx &cx, const Ray &ray, uint32_t nm, const GateBox &box0) {
+template <class CX>
+__device__ __forceinline__ uint32_t mesh_gates_pre(const CX &cx, const Ray &ray, uint32_t nm, const GateBox &box0) {
     if (nm == 0) return 0u;
 #ifdef HRT_ABL_NO_GATES  // ablation only
     return 0u;
 #endif
-    const f3 inv = ray_inv(ray);
-    uint32_t m = mesh_gate_box(box0, ray, inv) ? 1u : 0u;
+    const f3 inv = ray_inv<CX::exact>(ray);
+    uint32_t m = mesh_gate_box<CX::exact>(box0, ray, inv) ? 1u : 0u;
     for (uint32_t i = 1; i < nm; ++i)
-        if (mesh_gate((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
+        if (mesh_gate<CX::exact>((cmesh)cx.S->meshes + i, ray, inv)) m |= 1u << i;
     return m;
 }
 
 // The mesh loop of Scene::computeIntersection (Scene.h:222-228) over the meshes in `mask`.
-__device__ __forceinline__ void meshes_hit(const Ctx &cx, const Ray &ray, uint32_t mask, Hit &h) {
-    const f3 inv = ray_inv(ray);
+template <class CX>
+__device__ __forceinline__ void meshes_hit(const CX &cx, const Ray &ray, uint32_t mask, Hit &h) {
+    const f3 inv = ray_inv<CX::exact>(ray);
     const uint32_t nm = min(cx.S->n_meshes, 32u);
     for (uint32_t i = 0; i < nm; ++i) {  // wave-uniform loop: scalar mesh records
         if (mask & (1u << i)) {
@@ -520,7 +557,8 @@ __device__ __forceinline__ void meshes_hit(const Ctx &cx, const Ray &ray, uint32
 }
 
 // Scene::computeIntersection, Scene.h:202-230 (immediate form: AOV kernel).
-__device__ __forceinline__ Hit closest_hit(const Ctx &cx, const Ray &ray) {
+template <class CX>
+__device__ __forceinline__ Hit closest_hit(const CX &cx, const Ray &ray) {
     Hit h = prims_hit(cx, ray);
     const uint32_t m = mesh_gates(cx, ray);
     if (m) meshes_hit(cx, ray, m, h);
@@ -559,7 +597,8 @@ __device__ __forceinline__ uint64_t shadow_sphere_groups(cscene S, f3 p, f3 lpos
 // through with probability `transparency` (one draw per candidate).
 // Only the sphere groups in `groups` are tested (shadow_sphere_groups: no other sphere can be reached),
 // in ascending index order, so the draws fall exactly where the reference's full loop puts them.
-__device__ __forceinline__ bool shadow_blocked(const Ctx &cx, const Ray &ray, float tmax, Rng &rng, uint64_t groups, uint32_t gsize) {
+template <class CX>
+__device__ __forceinline__ bool shadow_blocked(const CX &cx, const Ray &ray, float tmax, Rng &rng, uint64_t groups, uint32_t gsize) {
     cscene S = cx.S;
     gf4 sph = (gf4)S->spheres;
     gf4 mats = (gf4)S->materials;
@@ -591,12 +630,12 @@ __device__ __forceinline__ bool shadow_blocked(const Ctx &cx, const Ray &ray, fl
     const uint32_t nm = min(S->n_meshes, 32u);
 #endif
     if (nm) {
-        const f3 inv = ray_inv(ray);
+        const f3 inv = ray_inv<CX::exact>(ray);
         for (uint32_t i = 0; i < nm; ++i) {
             cmesh M = (cmesh)S->meshes + i;
             float t, u, v;
             uint32_t tri;
-            if (mesh_gate(M, ray, inv) && mesh_traverse(cx, M, ray, inv, t, tri, u, v) && t < tmax && HRT_T_ACCEPT(t)) {
+            if (mesh_gate<CX::exact>(M, ray, inv) && mesh_traverse(cx, M, ray, inv, t, tri, u, v) && t < tmax && HRT_T_ACCEPT(t)) {
                 const float transparency = ld(mats, HRT_MAT_ROWS * M->material).w;
                 if (rng.next() > transparency) return true;
             }
@@ -651,6 +690,12 @@ __device__ __forceinline__ f3 mat_emit(cscene S, gf4 m, uint32_t tex_type, bool 
     return c * lc.w;
 }
 
+// Sphere.h:129-130 (fp64 libm as the reference)
+__device__ __forceinline__ void sphere_angles(f3 n, float &theta, float &phi) {
+    theta = (float)acos((double)n.y * -1.);
+    phi = (float)(atan2((double)n.z * -1., (double)n.x) + 3.14159265358979323846);
+}
+
 struct Surface {
     f3 p, n, albedo, emission;
     float transparency, index_medium;
@@ -677,8 +722,8 @@ __device__ __forceinline__ Surface shade(cscene S, const Ray &ray, const Hit &h)
         sf.n = normalize(p - c);
         sf.albedo = mk(m0);
         if (tex_type != 0u || emissive) {  // Sphere.h:129-130, Scene.h:275-277 (fp64 libm as the reference)
-            const float theta = (float)acos((double)sf.n.y * -1.);
-            const float phi = (float)(atan2((double)sf.n.z * -1., (double)sf.n.x) + 3.14159265358979323846);
+            float theta, phi;
+            sphere_angles(sf.n, theta, phi);
             const float u = (float)((double)phi / (2 * 3.14159265358979323846));
             const float v = (float)((double)theta / 3.14159265358979323846);
             sf.albedo = mat_texture(S, m, tex_type, sf.albedo, u, v);
@@ -785,7 +830,8 @@ __device__ __forceinline__ f3 sky(cscene S, f3 dir, int remaining) {
 }
 
 // Direct light with soft shadows, Scene.h:305-334.
-__device__ __forceinline__ f3 direct_light(const Ctx &cx, const Surface &sf, const Ray &ray, Rng &rng) {
+template <class CX>
+__device__ __forceinline__ f3 direct_light(const CX &cx, const Surface &sf, const Ray &ray, Rng &rng) {
     f3 color = mk(0.f, 0.f, 0.f);
     cf4 L = (cf4)cx.S->lights;
     const uint32_t nl = cx.S->n_lights;
@@ -798,7 +844,7 @@ __device__ __forceinline__ f3 direct_light(const Ctx &cx, const Surface &sf, con
         int blocked = 0;
         const float delta = l0.w / 2.f;
         const uint32_t gsize = (cx.S->n_spheres + 63u) / 64u;
-        const uint64_t groups = (cx.flags & HRT_FLAG_NO_SHADOW_CULL)
+        const uint64_t groups = (CX::exact || (cx.flags & HRT_FLAG_NO_SHADOW_CULL))
                                     ? ~0ull  // every group: the reference's full loop (tests compare the two bit for bit)
                                     : shadow_sphere_groups(cx.S, sf.p, lpos, fabsf(delta) * 1.0001f + 1e-6f, ray.time, gsize);
         for (int j = 0; j < 10; ++j) {  // NB_ECH
@@ -834,6 +880,7 @@ __device__ __forceinline__ float div_narrow(double r, double d, double inv_d) {
     const float lo = (float)(q * (1.0 - 8.881784197001252e-16)), hi = (float)(q * (1.0 + 8.881784197001252e-16));  // 1 -+ 2^-50
     return (lo == hi) ? lo : (float)(r / d);
 }
+template <bool EXACT = false>
 __device__ __forceinline__ Ray camera_ray(ccam C, float u, float v, float time) {
     const double ri0 = C->pi0 * (2.0 * (double)u - 1.0);
     const double ri1 = C->pi5 * -(2.0 * (double)v - 1.0);
@@ -841,7 +888,8 @@ __device__ __forceinline__ Ray camera_ray(ccam C, float u, float v, float time) 
     const double r0 = ((C->mx[0] * ri0 + C->my[0] * ri1) + C->c1[0]) + C->c2[0];
     const double r1 = ((C->mx[1] * ri0 + C->my[1] * ri1) + C->c1[1]) + C->c2[1];
     const double r2 = ((C->mx[2] * ri0 + C->my[2] * ri1) + C->c1[2]) + C->c2[2];
-    const f3 world = mk(div_narrow(r0, d, inv_d), div_narrow(r1, d, inv_d), div_narrow(r2, d, inv_d));
+    const f3 world = EXACT ? mk((float)(r0 / d), (float)(r1 / d), (float)(r2 / d))  // matrixUtilities.h:66-68 as written
+                           : mk(div_narrow(r0, d, inv_d), div_narrow(r1, d, inv_d), div_narrow(r2, d, inv_d));
     Ray out;
     out.o = mk(C->eye[0], C->eye[1], C->eye[2]);
     // normalised twice, as the reference does: once in screen_space_to_world_space_ray
@@ -855,10 +903,10 @@ __device__ __forceinline__ Ray camera_ray(ccam C, float u, float v, float time) 
 // The megakernel body.  LIGHTS = the scene has point lights (soft-shadow fan-out, Scene.h:305-334,
 // compiled in); scenes without lights run the variant that carries none of that code or its registers.
 // ---------------------------------------------------------------------------
-template <bool LIGHTS>
+template <bool LIGHTS, bool EXACT = false>
 __device__ __forceinline__ void trace_body(const DRender &R) {
     extern __shared__ uint4 s_units[];
-    Ctx cx;
+    CtxT<EXACT> cx;
     cx.S = (cscene)R.scene;
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
@@ -916,7 +964,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                     const float u = ((float)px + rng.next()) / (float)R.w;
                     const float v = ((float)py + rng.next()) / (float)R.h;
                     const float tm = rng.next();
-                    ray = camera_ray(cam, u, v, tm);
+                    ray = camera_ray<EXACT>(cam, u, v, tm);
                     thr = mk(1.f, 1.f, 1.f);
                     rad = mk(0.f, 0.f, 0.f);
                     remaining = 6;  // MAXBOUNCES
@@ -994,6 +1042,9 @@ using namespace hrtk;
 
 extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES_SINGLE) hrt_trace_kernel(const DRender R) { trace_body<false>(R); }
 extern "C" __global__ void __launch_bounds__(HRT_WG, HRT_MIN_WAVES_SINGLE_LIGHTS) hrt_trace_kernel_lights(const DRender R) { trace_body<true>(R); }
+// HRT_FLAG_EXACT_ONLY: the proof builds (no filters, no v_rcp_f32; see CtxT).  Not tuned: 2 waves per SIMD.
+extern "C" __global__ void __launch_bounds__(HRT_WG, 2) hrt_trace_kernel_exact(const DRender R) { trace_body<false, true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_WG, 2) hrt_trace_kernel_lights_exact(const DRender R) { trace_body<true, true>(R); }
 
 // gamma_correct (Functions.cpp:56-60): pow(c, 1/2.2) in double, over this rank's tile buffer.  Kept out of
 // the megakernel: fp64 pow is register-hungry and runs once per pixel.

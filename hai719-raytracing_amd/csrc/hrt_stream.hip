@@ -152,7 +152,7 @@ __device__ __forceinline__ Hit sp_load_hit(const SpLds &L, uint32_t slot) {
     return h;
 }
 
-template <bool LIGHTS>
+template <bool LIGHTS, bool EXACT = false>
 __device__ __forceinline__ void stream_body(const DRender &R) {
     extern __shared__ uint4 s_raw[];
     SpLds L;
@@ -167,7 +167,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     L.run = reinterpret_cast<float *>(L.ctl + 1);
     uint32_t *tile_xy = reinterpret_cast<uint32_t *>(L.run + HRT_SP_MAXG * 192);  // x0 | y0 << 16 per tile of the unit, ~0: no tile
     uint4 *s_units = reinterpret_cast<uint4 *>(tile_xy + HRT_SP_MAXG);  // 16-byte aligned: every size above is a multiple of 16
-    Ctx cx;
+    CtxT<EXACT> cx;
     cx.S = (cscene)R.scene;
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
@@ -332,7 +332,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 const float u = ((float)px + rng.next()) / (float)R.w;
                                 const float v = ((float)py + rng.next()) / (float)R.h;
                                 const float tm = rng.next();
-                                ray = camera_ray(cam, u, v, tm);
+                                ray = camera_ray<EXACT>(cam, u, v, tm);
                                 spf(L, SP_TM, slot) = tm;
                                 spf(L, SP_TR, slot) = 1.f; spf(L, SP_TG, slot) = 1.f; spf(L, SP_TB, slot) = 1.f;
                                 spf(L, SP_RR, slot) = 0.f; spf(L, SP_RG, slot) = 0.f; spf(L, SP_RB, slot) = 0.f;
@@ -460,3 +460,6 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 
 extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel(const DRender R) { hrtk::stream_body<false>(R); }
 extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_lights(const DRender R) { hrtk::stream_body<true>(R); }
+// HRT_FLAG_EXACT_ONLY proof builds (no filters, no v_rcp_f32; CtxT in hrt_kernels.hip)
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_exact(const DRender R) { hrtk::stream_body<false, true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_lights_exact(const DRender R) { hrtk::stream_body<true, true>(R); }

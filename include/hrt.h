@@ -162,7 +162,16 @@ enum {
     HRT_FLAG_WAVE_KERNEL = 4u, /* force the one-pixel-per-lane kernel                                             */
     HRT_FLAG_STREAM_KERNEL = 8u, /* force the workgroup-streaming kernel (the default for scenes with meshes or lights) */
     HRT_FLAG_NO_SHADOW_CULL = 16u, /* debug: shadow rays test every sphere (the reference's loop) instead of the culled groups */
-    HRT_FLAG_DUAL_KERNEL = 32u /* force the two-streams-per-lane kernel (mesh scenes; all kernel forms give identical pixels) */
+    HRT_FLAG_DUAL_KERNEL = 32u, /* force the two-streams-per-lane kernel (mesh scenes; all kernel forms give identical pixels) */
+    /* Proof builds of the lane-per-pixel and streaming kernels: no filter and no reciprocal approximation anywhere in
+     * front of the reference arithmetic.  Every square goes through Square::intersect's arithmetic in index order
+     * (Square.h:65-126, Scene.h:214-221), every mesh gate through AABB::intersects' fp64 form (AABB.h:48-65,
+     * KDTree.cpp:82), shadow rays test every sphere (Scene.h:235-255), the camera quotient is a true fp64 division
+     * (matrixUtilities.h:66-68).  Slow; exists so tests can show that the default path's filters never change a pixel. */
+    HRT_FLAG_EXACT_ONLY = 64u,
+    /* With HRT_FLAG_EXACT_ONLY: meshes are not walked through the KD-tree at all -- every triangle of a gated mesh is
+     * tested (Mesh::intersectOld, Mesh.h:257-277).  Shows that the rope walk never skips the closest triangle. */
+    HRT_FLAG_MESH_BRUTE = 128u
 };
 
 typedef struct hrt_stats {
@@ -218,6 +227,24 @@ int hrt_render_aov(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t
 /* Draws 0..n-1 of the per-path RNG stream (seed, pixel, sample) as the kernel
  * produces them (DESIGN.md "RNG stream").  out: host, n floats. */
 int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out);
+
+/* Known-answer instrument: runs the DEVICE functions of the trace path on caller vectors (one lane each), so that a test
+ * can compare the device arithmetic bit for bit with vectors produced by the reference's own code instead of inferring
+ * it from pixels.  `in` holds n rows, `out` receives n rows (host memory); rays are {origin, direction, time} and get
+ * the Ray constructor's normalisation (Line.h:13-16).
+ *   which             cam / prim                                in row   out row
+ *   HRT_KAT_CAMERA    cam                                       u, v     12: Ray origin + direction (main.cpp:189-192,
+ *                                                                        matrixUtilities.h:53-74), then the same from
+ *                                                                        the exact-division build (must be equal)
+ *   HRT_KAT_TRIANGLE  prim = c0, c1, c2 (Triangle ctor)         ray 7    8: hit, t, w0, w1, w2, normal (Triangle.h:77-126)
+ *   HRT_KAT_AABB      prim = lo, hi                             ray 7    2: AABB::intersects (AABB.h:48-65), shipped gate
+ *   HRT_KAT_SPHERE    prim = centre, radius, motion             ray 7    9: hit, t, theta, phi, normal, p.x, p.y (Sphere.h:91-132)
+ *   HRT_KAT_QUAD      prim = v0, v1, v3, motion, glass          ray 7    8: hit, t, u, v, normal (Square.h:65-126), filter bit
+ *   HRT_KAT_OPTICS    -                                         d, n, eta, cosine   8: reflect, refract, reflectance, gamma(|cosine|)
+ *   HRT_KAT_NORMALIZE -                                         v        3: v / |v| (Vec3.h:46) */
+enum { HRT_KAT_CAMERA = 0, HRT_KAT_TRIANGLE = 1, HRT_KAT_AABB = 2, HRT_KAT_SPHERE = 3, HRT_KAT_QUAD = 4, HRT_KAT_OPTICS = 5,
+       HRT_KAT_NORMALIZE = 6 };
+int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, const float *in, uint32_t n, float *out);
 
 /* Cycle counters per kernel stage of the last launch; all zero unless libhrt.so was built with
  * -DHRT_STAMPS (diagnostic build, tools/variants.sh).  out: 16 values. */

@@ -515,8 +515,24 @@ struct SceneHit {
     TriHit tri;
 };
 
+// Debug instrument (oracle_trace_path): when set, every closest-hit query of this thread appends
+// {o.xyz, d.xyz, time, kind, index, t, tIndex, 0} (12 floats) here.
+thread_local float *g_trace = nullptr;
+thread_local uint32_t g_trace_n = 0, g_trace_cap = 0;
+
+SceneHit compute_intersection_impl(const OScene &S, const Ray &ray, Counters *cnt);
 // Scene::computeIntersection, Scene.h:202-230
 SceneHit compute_intersection(const OScene &S, const Ray &ray, Counters *cnt) {
+    SceneHit res = compute_intersection_impl(S, ray, cnt);
+    if (g_trace && g_trace_n < g_trace_cap) {
+        float *o = g_trace + 12 * (size_t)g_trace_n++;
+        o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z; o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z; o[6] = ray.time;
+        o[7] = (float)res.kind; o[8] = (float)res.index; o[9] = res.kind ? res.t : 0.f;
+        o[10] = res.kind == 3 ? (float)res.tri.tIndex : -1.f; o[11] = 0.f;
+    }
+    return res;
+}
+SceneHit compute_intersection_impl(const OScene &S, const Ray &ray, Counters *cnt) {
     SceneHit res;
     const hrt_scene_desc &d = *S.d;
     if (cnt) cnt->closest_queries++;
@@ -680,23 +696,44 @@ struct CameraMats {
     double mv_inv[16], p_inv[16];  // column-major like GL
 };
 
-bool invert4(const double m[16], double out[16]) {  // generic Gauss-Jordan in place of gluInvertMatrix :77-206
-    double a[4][8];
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) { a[r][c] = m[c * 4 + r]; a[r][c + 4] = (r == c) ? 1.0 : 0.0; }
-    for (int col = 0; col < 4; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
-        if (a[piv][col] == 0.0) return false;
-        if (piv != col) for (int c = 0; c < 8; ++c) std::swap(a[piv][c], a[col][c]);
-        double inv = 1.0 / a[col][col];
-        for (int c = 0; c < 8; ++c) a[col][c] *= inv;
-        for (int r = 0; r < 4; ++r) if (r != col) {
-            double f = a[r][col];
-            if (f != 0.0) for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+// gluInvertMatrix, matrixUtilities.h:77-206: the adjugate over the determinant.  Entry e of the adjugate is a sum of six
+// signed triple products, evaluated left to right -- ((s*m[a]) * m[b]) * m[c], terms added in the order written (a
+// subtraction is the addition of the negated product, which rounds identically).  The table lists the terms of every
+// entry in the reference's order, so each entry rounds exactly as the reference's; bit-exactness against the reference's
+// own function is checked by tests/test_oracle_pins.py (live and through tests/golden/ref_kat.npz).
+static const signed char kAdjugate[16][6][4] = {
+    {{1, 5, 10, 15}, {-1, 5, 11, 14}, {-1, 9, 6, 15}, {1, 9, 7, 14}, {1, 13, 6, 11}, {-1, 13, 7, 10}},
+    {{-1, 1, 10, 15}, {1, 1, 11, 14}, {1, 9, 2, 15}, {-1, 9, 3, 14}, {-1, 13, 2, 11}, {1, 13, 3, 10}},
+    {{1, 1, 6, 15}, {-1, 1, 7, 14}, {-1, 5, 2, 15}, {1, 5, 3, 14}, {1, 13, 2, 7}, {-1, 13, 3, 6}},
+    {{-1, 1, 6, 11}, {1, 1, 7, 10}, {1, 5, 2, 11}, {-1, 5, 3, 10}, {-1, 9, 2, 7}, {1, 9, 3, 6}},
+    {{-1, 4, 10, 15}, {1, 4, 11, 14}, {1, 8, 6, 15}, {-1, 8, 7, 14}, {-1, 12, 6, 11}, {1, 12, 7, 10}},
+    {{1, 0, 10, 15}, {-1, 0, 11, 14}, {-1, 8, 2, 15}, {1, 8, 3, 14}, {1, 12, 2, 11}, {-1, 12, 3, 10}},
+    {{-1, 0, 6, 15}, {1, 0, 7, 14}, {1, 4, 2, 15}, {-1, 4, 3, 14}, {-1, 12, 2, 7}, {1, 12, 3, 6}},
+    {{1, 0, 6, 11}, {-1, 0, 7, 10}, {-1, 4, 2, 11}, {1, 4, 3, 10}, {1, 8, 2, 7}, {-1, 8, 3, 6}},
+    {{1, 4, 9, 15}, {-1, 4, 11, 13}, {-1, 8, 5, 15}, {1, 8, 7, 13}, {1, 12, 5, 11}, {-1, 12, 7, 9}},
+    {{-1, 0, 9, 15}, {1, 0, 11, 13}, {1, 8, 1, 15}, {-1, 8, 3, 13}, {-1, 12, 1, 11}, {1, 12, 3, 9}},
+    {{1, 0, 5, 15}, {-1, 0, 7, 13}, {-1, 4, 1, 15}, {1, 4, 3, 13}, {1, 12, 1, 7}, {-1, 12, 3, 5}},
+    {{-1, 0, 5, 11}, {1, 0, 7, 9}, {1, 4, 1, 11}, {-1, 4, 3, 9}, {-1, 8, 1, 7}, {1, 8, 3, 5}},
+    {{-1, 4, 9, 14}, {1, 4, 10, 13}, {1, 8, 5, 14}, {-1, 8, 6, 13}, {-1, 12, 5, 10}, {1, 12, 6, 9}},
+    {{1, 0, 9, 14}, {-1, 0, 10, 13}, {-1, 8, 1, 14}, {1, 8, 2, 13}, {1, 12, 1, 10}, {-1, 12, 2, 9}},
+    {{-1, 0, 5, 14}, {1, 0, 6, 13}, {1, 4, 1, 14}, {-1, 4, 2, 13}, {-1, 12, 1, 6}, {1, 12, 2, 5}},
+    {{1, 0, 5, 10}, {-1, 0, 6, 9}, {-1, 4, 1, 10}, {1, 4, 2, 9}, {1, 8, 1, 6}, {-1, 8, 2, 5}}};
+
+bool invert4(const double m[16], double out[16]) {
+    double adj[16];
+    for (int e = 0; e < 16; ++e) {
+        double sum = 0.0;
+        for (int k = 0; k < 6; ++k) {
+            const signed char *t = kAdjugate[e][k];
+            const double term = ((t[0] < 0 ? -m[t[1]] : m[t[1]]) * m[t[2]]) * m[t[3]];
+            sum = k == 0 ? term : sum + term;
         }
+        adj[e] = sum;
     }
-    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[c * 4 + r] = a[r][c + 4];
+    double det = m[0] * adj[0] + m[1] * adj[4] + m[2] * adj[8] + m[3] * adj[12];  // :195
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int e = 0; e < 16; ++e) out[e] = adj[e] * det;
     return true;
 }
 
@@ -707,9 +744,10 @@ inline void mult4(const double m[16], double x, double y, double z, double w, do
     r[3] = m[3] * x + m[7] * y + m[11] * z + m[15] * w;
 }
 
-CameraMats camera_matrices(const hrt_camera &c) {
+// The GL matrices the reference would read back (matrixUtilities.h:33-46) for the pose an hrt_camera describes:
+void camera_forward_matrices(const hrt_camera &c, double mv[16], double p[16]) {
+    for (int k = 0; k < 16; ++k) { mv[k] = 0.0; p[k] = 0.0; }
     // modelview = [right; up; -forward] * translate(-eye)   (Camera.cpp:125-132 composes the same for the default pose)
-    double mv[16] = {0}, p[16] = {0};
     const double R[3][3] = {{c.right[0], c.right[1], c.right[2]},
                             {c.up[0], c.up[1], c.up[2]},
                             {-(double)c.forward[0], -(double)c.forward[1], -(double)c.forward[2]}};
@@ -727,6 +765,11 @@ CameraMats camera_matrices(const hrt_camera &c) {
     p[10] = -((double)c.zfar + (double)c.znear) / dz;
     p[11] = -1.0;
     p[14] = -2.0 * (double)c.znear * (double)c.zfar / dz;
+}
+
+CameraMats camera_matrices(const hrt_camera &c) {
+    double mv[16], p[16];
+    camera_forward_matrices(c, mv, p);
     CameraMats out;
     invert4(mv, out.mv_inv);
     invert4(p, out.p_inv);
@@ -961,6 +1004,13 @@ void oracle_kat_optics(const float *in, uint32_t n, float *out) {
         o[7] = gamma_channel(std::fabs(a[7]));
     }
 }
+// Ray constructor normalisation (Line.h:13-16, Vec3.h:46): in n x 3 -> out n x 3
+void oracle_kat_normalize(const float *in, uint32_t n, float *out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const Ray r = make_ray(v3(0.f, 0.f, 0.f), v3(in + 3 * (size_t)i), 0.f);
+        out[3 * i] = r.d.x; out[3 * i + 1] = r.d.y; out[3 * i + 2] = r.d.z;
+    }
+}
 // random_float / random_unit_vector as the reference defines them (Functions.cpp:4-18) on an
 // mt19937 seeded with `seed` (the reference seeds with time(nullptr)); out n x 4 = float, unit vector.
 // Argument evaluation order of Vec3(random_float(),random_float(),random_float()) is unspecified in
@@ -983,14 +1033,39 @@ void oracle_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t
     PathRng rng(seed, pixel, sample, nullptr);
     for (uint32_t i = 0; i < n; ++i) out[i] = rng.next();
 }
+// Debug instrument: the closest-hit queries of ONE path (pixel x,y, sample s) in order -- up to `cap` records of 12 floats
+// {ray o, d, time, hit kind, object index, t, triangle id, 0}.  Returns the number of records.
+uint32_t oracle_trace_path(const oracle_scene *o, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t x, uint32_t y,
+                           uint32_t sample, uint64_t seed, float *out, uint32_t cap) {
+    const CameraMats cm = camera_matrices(*cam);
+    PathRng rng(seed, y * w + x, sample, nullptr);
+    float u = ((float)x + rng.next()) / w;
+    float v = ((float)y + rng.next()) / h;
+    V3 pos, dir;
+    camera_ray(cm, u, v, pos, dir);
+    float time = rng.next();
+    g_trace = out; g_trace_n = 0; g_trace_cap = cap;
+    (void)ray_trace(o->S, make_ray(pos, dir, time), rng, nullptr);
+    g_trace = nullptr;
+    return g_trace_n;
+}
+
+// out: 64 doubles = modelview, projection (what the reference's GL read-back would hold), their inverses
+void oracle_camera_matrices(const hrt_camera *cam, double *out) {
+    camera_forward_matrices(*cam, out, out + 16);
+    invert4(out, out + 32);
+    invert4(out + 16, out + 48);
+}
+
 // camera rays through (u,v): uv n x 2 -> out n x 6 (pos, dir)
 void oracle_camera_rays(const hrt_camera *cam, const float *uv, uint32_t n, float *out) {
     CameraMats cm = camera_matrices(*cam);
     for (uint32_t i = 0; i < n; ++i) {
         V3 p, d;
         camera_ray(cm, uv[2 * i], uv[2 * i + 1], p, d);
+        const Ray r = make_ray(p, d, 0.f);  // main.cpp:192: the Ray constructor normalises once more (Line.h:13-16)
         float *o = out + 6 * (size_t)i;
-        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = d.x; o[4] = d.y; o[5] = d.z;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
     }
 }
 

@@ -3,6 +3,8 @@
 // reference that compile from their own sources with g++ alone:
 //     src/Vec3.h  src/Ray.h  src/Line.h  src/AABB.h  src/Triangle.h
 //     src/Functions.{h,cpp}  src/imageLoader.{h,cpp}
+//     src/matrixUtilities.h  (needs <GL/gl.h> + libGL, both in the image; no GL call is made at run time because
+//                             the *Updated flags stay false, so no context is needed)
 // The sources are compiled WHERE THEY LIE under /root/reference (never copied);
 // the output goes to oracle/_ref/ (git-ignored).  Sphere.h, Square.h, Mesh.*,
 // Material.*, KDTree.*, Scene.h and main.cpp include <GL/glut.h>, which this
@@ -18,6 +20,7 @@
 #include "src/Triangle.h"
 #include "src/Functions.h"
 #include "src/imageLoader.h"
+#include "src/matrixUtilities.h"
 
 // random_float() seeds its static mt19937 with time(nullptr) (Functions.cpp:6).
 // Interposing time() fixes that seed without touching the reference source.
@@ -91,6 +94,32 @@ void ref_kat_normalize(const float *in, uint32_t n, float *out) {
         Ray r(Vec3(0, 0, 0), Vec3(in[3 * i], in[3 * i + 1], in[3 * i + 2]), 0.f);
         out[3 * i] = r.direction()[0]; out[3 * i + 1] = r.direction()[1]; out[3 * i + 2] = r.direction()[2];
     }
+}
+
+// Camera rays of main.cpp:189-192 from given GL matrices (column-major doubles, what glGetDoublev would have
+// returned): the reference's own gluInvertMatrix (matrixUtilities.h:77-206), screen_space_to_world_space_ray
+// (:53-74) and the Ray constructor's second normalisation (Line.h:13-16).  GL_DEPTH_RANGE reads {0, 1} by default.
+// uv: n x 2 -> out: n x 6 (Ray origin, Ray direction).  Returns 0 when a matrix is singular.
+int ref_camera_rays(const double modelview[16], const double projection[16], const float *uv, uint32_t n, float *out) {
+    MatrixUtilities mu;  // the constructor's updateMatrices() does nothing: all three flags are false
+    for (int k = 0; k < 16; ++k) { mu.modelview[k] = modelview[k]; mu.projection[k] = projection[k]; }
+    if (!gluInvertMatrix(mu.modelview, mu.modelviewInverse)) return 0;   // what updateMatrices() does after the read-back (:36, :42)
+    if (!gluInvertMatrix(mu.projection, mu.projectionInverse)) return 0;
+    mu.nearAndFarPlanes[0] = 0.0;
+    mu.nearAndFarPlanes[1] = 1.0;
+    for (uint32_t i = 0; i < n; ++i) {
+        Vec3 pos, dir;
+        mu.screen_space_to_world_space_ray(uv[2 * i], uv[2 * i + 1], pos, dir);
+        Ray ray(pos, dir, 0.f);
+        float *o = out + 6 * (size_t)i;
+        o[0] = ray.origin()[0]; o[1] = ray.origin()[1]; o[2] = ray.origin()[2];
+        o[3] = ray.direction()[0]; o[4] = ray.direction()[1]; o[5] = ray.direction()[2];
+    }
+    return 1;
+}
+// the two inverses themselves: out 32 doubles
+int ref_camera_inverses(const double modelview[16], const double projection[16], double *out) {
+    return (gluInvertMatrix(modelview, out) && gluInvertMatrix(projection, out + 16)) ? 1 : 0;
 }
 
 // PPM loader: returns w*h (0 on failure) and a checksum of the bytes

@@ -7,6 +7,10 @@ ref_kat.npz       inputs + outputs of the reference's OWN code (oracle/_ref/libr
                   from /root/reference/src/{Triangle.h,AABB.h,Functions.cpp,Vec3.h,Ray.h,Line.h}):
                   triangle / AABB intersection, reflect / refract / reflectance / gamma,
                   Ray normalisation, random_float / random_unit_vector on the fixed mt19937 seed.
+                  camera rays + both matrix inverses from the reference's matrixUtilities.h (gluInvertMatrix,
+                  screen_space_to_world_space_ray) for 16 poses.
+oracle_kat.npz    sphere / square known answers produced by the ORACLE (unpinned: Sphere.h / Square.h cannot be
+                  compiled here); they tie the HIP device functions to the restatement.
 ref_ppm.json      reference PPM loader (imageLoader.cpp) w, h and FNV-1a checksum of every asset image.
 oracle_images.npz oracle renders + AOVs of the config scenes at test size (fixed seed), so the GPU
                   box checks the HIP path against committed pixels as well as the live oracle.
@@ -57,7 +61,42 @@ def main():
     g["normalize_in"], g["normalize_out"] = v, out
     g["random_seed"] = np.array([R.ref_fixed_seed()], np.uint32)
     g["random_out"] = O.kat_random(2048, use_ref=True)   # first call in this process: the stream starts at the seed
+    # camera rays (row a2): the reference's gluInvertMatrix + screen_space_to_world_space_ray + Ray constructor
+    # (matrixUtilities.h:53-74, 77-206, compiled where it lies) on the GL matrices of each pose
+    crng = np.random.default_rng(20261004)
+    cams = [hrt.default_camera(1.0), hrt.default_camera(16 / 9), hrt.default_camera(64 / 36), hrt.default_camera(3840 / 2160)]
+    for _ in range(12):
+        cam = hrt.default_camera(1.0)
+        q, _r = np.linalg.qr(crng.normal(size=(3, 3)))
+        cam.right[:] = q[0].astype(np.float32); cam.up[:] = q[1].astype(np.float32); cam.forward[:] = q[2].astype(np.float32)
+        cam.eye[:] = crng.uniform(-10, 10, 3).astype(np.float32)
+        cam.fovy_deg = float(np.float32(crng.uniform(20, 100))); cam.aspect = float(np.float32(crng.uniform(0.5, 2.5)))
+        cams.append(cam)
+    uv = crng.uniform(0, 1, (1024, 2)).astype(np.float32)
+    uv[:4] = [[0, 0], [1, 1], [0.5, 0.5], [0, 1]]
+    g["camera_rows"] = np.stack([O.camera_to_row(c) for c in cams])
+    g["camera_uv"] = uv
+    g["camera_rays"] = np.stack([O.ref_camera_rays(c, uv) for c in cams])
+    g["camera_inverses"] = np.stack([np.concatenate(O.ref_camera_inverses(c)) for c in cams])
     np.savez_compressed(os.path.join(HERE, "ref_kat.npz"), **g)
+
+    # sphere / square known answers from the ORACLE (Sphere.h and Square.h include <GL/glut.h>: the reference cannot
+    # produce them here, so these are "parity unpinned" vectors: they pin the HIP path to the restatement, not to the reference)
+    k = {}
+    sph = np.array([[0, 0, 0, 1, 0, 0, 0], [0.3, -0.2, 0.5, 0.75, 0, 0.6, 0], [-1, 0.5, -2, 2.5, 0.2, 0, -0.1], [0, 0, 2, 1.5, 0, 0, 0]], np.float32)
+    rs = rays(rng, 2048)
+    rs[:4, :3] = [[0, 0, 2], [0, 0, 2], [0, 1, 2], [5, 5, 2]]; rs[:4, 3:6] = [[0, 0, -1], [0, 0, 1], [0, 0, -1], [0, 0, -1]]
+    k["sphere_prims"], k["sphere_rays"] = sph, rs
+    k["sphere_out"] = np.stack([O.kat("sphere", s_, rs) for s_ in sph])
+    quads = np.array([[-1, -1, 0, 1, -1, 0, -1, 1, 0, 0, 0, 0, 0],          # facing +z, static
+                      [-1, -1, 0, -1, 1, 0, 1, -1, 0, 0, 0, 0, 0],          # facing -z: culled for -z rays
+                      [-1, -1, 0, -1, 1, 0, 1, -1, 0, 0, 0, 0, 1],          # the same, glass: hit from behind
+                      [-0.5, -0.8, -0.3, 1.2, -0.6, 0.1, -0.7, 0.9, 0.4, 0.1, 0.4, -0.2, 0]], np.float32)  # tilted, moving
+    rq = rays(rng, 2048)
+    rq[:4, :3] = [[0, 0, 2], [-1, -1, 2], [1, 1, 2], [0.99999, 0, 2]]; rq[:4, 3:6] = [[0, 0, -1]] * 4
+    k["quad_prims"], k["quad_rays"] = quads, rq
+    k["quad_out"] = np.stack([O.kat("quad", q_, rq) for q_ in quads])
+    np.savez_compressed(os.path.join(HERE, "oracle_kat.npz"), **k)
 
     import ctypes as C
     ppm = {}

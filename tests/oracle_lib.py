@@ -54,6 +54,12 @@ def lib() -> C.CDLL:
         L.oracle_path_stream.restype = None
         L.oracle_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_camera_rays.restype = None
+        L.oracle_camera_matrices.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_camera_matrices.restype = None
+        L.oracle_kat_normalize.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.oracle_kat_normalize.restype = None
+        L.oracle_trace_path.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 5 + [C.c_uint64, C.c_void_p, C.c_uint32]
+        L.oracle_trace_path.restype = C.c_uint32
         _lib = L
     return _lib
 
@@ -76,6 +82,10 @@ def ref_parts():
         R.ref_kat_random.restype = None
         R.ref_kat_normalize.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         R.ref_kat_normalize.restype = None
+        R.ref_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        R.ref_camera_rays.restype = C.c_int
+        R.ref_camera_inverses.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        R.ref_camera_inverses.restype = C.c_int
         R.ref_ppm_info.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         R.ref_ppm_info.restype = C.c_uint64
         _ref = R
@@ -171,3 +181,56 @@ def camera_rays(cam, uv):
     out = np.empty((uv.shape[0], 6), dtype=np.float32)
     lib().oracle_camera_rays(C.byref(cam), uv.ctypes.data, uv.shape[0], out.ctypes.data)
     return out
+
+
+def camera_matrices(cam):
+    """(modelview, projection, modelview^-1, projection^-1), column-major doubles, as the oracle builds them."""
+    m = np.zeros(64, np.float64)
+    lib().oracle_camera_matrices(C.byref(cam), m.ctypes.data)
+    return m[:16].copy(), m[16:32].copy(), m[32:48].copy(), m[48:].copy()
+
+
+def ref_camera_rays(cam, uv):
+    """The reference's own gluInvertMatrix + screen_space_to_world_space_ray + Ray constructor (oracle/_ref) on the GL
+    matrices of `cam`: (n, 6) origin + direction."""
+    mv, pr, _, _ = camera_matrices(cam)
+    uv = _f32(uv)
+    out = np.empty((uv.shape[0], 6), dtype=np.float32)
+    assert ref_parts().ref_camera_rays(mv.ctypes.data, pr.ctypes.data, uv.ctypes.data, uv.shape[0], out.ctypes.data) == 1
+    return out
+
+
+def ref_camera_inverses(cam):
+    mv, pr, _, _ = camera_matrices(cam)
+    out = np.zeros(32, np.float64)
+    assert ref_parts().ref_camera_inverses(mv.ctypes.data, pr.ctypes.data, out.ctypes.data) == 1
+    return out[:16], out[16:]
+
+
+def kat_normalize(v):
+    v = _f32(v)
+    out = np.empty_like(v)
+    lib().oracle_kat_normalize(v.ctypes.data, v.shape[0], out.ctypes.data)
+    return out
+
+
+CAMERA_FIELDS = 16  # eye, right, up, forward (3 each), fovy_deg, aspect, znear, zfar
+
+
+def camera_to_row(cam):
+    return np.array(list(cam.eye) + list(cam.right) + list(cam.up) + list(cam.forward) + [cam.fovy_deg, cam.aspect, cam.znear, cam.zfar],
+                    np.float32)
+
+
+def camera_from_row(hrt, row):
+    cam = hrt.Camera()
+    cam.eye[:] = row[0:3]; cam.right[:] = row[3:6]; cam.up[:] = row[6:9]; cam.forward[:] = row[9:12]
+    cam.fovy_deg, cam.aspect, cam.znear, cam.zfar = (float(x) for x in row[12:16])
+    return cam
+
+
+def trace_path(scene, cam, w, h, x, y, sample, seed, cap=8):
+    """Debug: the closest-hit queries of one path, rows of {o, d, time, kind, index, t, triangle, 0}."""
+    out = np.zeros((cap, 12), np.float32)
+    n = lib().oracle_trace_path(scene._h, C.byref(cam), w, h, x, y, sample, seed, out.ctypes.data, cap)
+    return out[:n]

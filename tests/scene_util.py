@@ -1,0 +1,34 @@
+"""Synthetic scenes shared by the GPU tests (host layer only: no GPU, no oracle)."""
+import numpy as np
+
+
+def many_squares(gpu, n_quads, n_meshes):
+    """A random cloud of small tilted squares (some glass, some mirror, some moving) over a floor, tetrahedra as meshes,
+    one point light: exercises the 32-bit / 64-bit candidate masks of the square filter and the bypass beyond 64."""
+    M = gpu.Material.make
+    rng = np.random.default_rng(100 + n_quads)
+    s = gpu.HostScene()
+    s.set_sky(False)
+    s.add_light((0.0, 4.0, 3.0), 1.0)
+    s.add_quad((-6, -2, -8), (1, 0, 0), (0, 0, 1), 12, 12, M(albedo=(0.8, 0.8, 0.8)))
+    for i in range(n_quads - 1):
+        c = rng.uniform((-3, -1.5, -6), (3, 2.0, -1))
+        r = rng.normal(size=3); u = np.cross(r, rng.normal(size=3))
+        kind = i % 5
+        mat = M(albedo=tuple(rng.uniform(0.2, 1, 3)), type=gpu.MAT_GLASS if kind == 0 else (gpu.MAT_MIRROR if kind == 1 else gpu.MAT_DIFFUSE),
+                transparency=0.5 if kind == 0 else 0.0, index_medium=1.4, motion=(0.0, 0.3, 0.0) if kind == 2 else (0, 0, 0))
+        s.add_quad(tuple(c), tuple(r), tuple(u), float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9)), mat)
+    tet = np.array([[0, 0, 0], [0.6, 0, 0], [0.3, 0.6, 0.1], [0.3, 0.2, 0.6]], np.float32)
+    tri = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]], np.uint32)
+    for i in range(n_meshes):
+        s.add_mesh(tet + rng.uniform((-3, -1.5, -5), (3, 1.5, -1.5)).astype(np.float32), tri, M(albedo=tuple(rng.uniform(0.2, 1, 3))))
+    return s
+
+
+def describe_difference(a, b):
+    """Text for an assertion message: how many pixels differ and by how much."""
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    bad = (a != b).any(axis=2)
+    n = int(bad.sum())
+    where = np.argwhere(bad)[:5].tolist()
+    return f"{n} of {bad.size} pixels differ, max |diff| {d.max():.3g}, first at (y, x) {where}"

@@ -1,0 +1,65 @@
+"""The default path's FILTERS against the proof builds, at frame scale (VERDICT r1 "what's weak" 2).
+
+The shipped kernels put three cheap, approximate selections in front of the reference arithmetic:
+  * quad_filter      no-division plane/inside test with margins -> which squares go through Square::intersect's arithmetic
+  * mesh_gate_box    fp32 slab test with a margin                -> which rays skip AABB::intersects' fp64 form
+  * shadow capsule   which sphere groups a shadow ray can reach
+plus v_rcp_f32 reciprocals inside the KD walk and a multiply-by-reciprocal fast path of the camera quotient.
+DESIGN.md claims none of them ever decides a hit.  HRT_FLAG_EXACT_ONLY runs builds of the same kernels with all of that
+compiled out (every square exactly and in index order, every gate in fp64, every sphere for every shadow ray, IEEE
+divisions); HRT_FLAG_MESH_BRUTE additionally replaces the KD walk by a loop over every triangle.  The frames must be
+bit-identical: one false negative of a filter anywhere in ~10^8 paths x 6 bounces changes a path and therefore a pixel.
+"""
+import numpy as np
+import pytest
+
+from scene_util import describe_difference, many_squares
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(gpu, name, aspect):
+    if name.startswith("many_squares"):
+        _, nq, nm = name.split(":")
+        host = many_squares(gpu, int(nq), int(nm))
+    else:
+        host = gpu.HostScene().setup(name, aspect, 1)
+    desc = host.flatten()
+    return host, desc, gpu.DeviceScene(desc), gpu.default_camera(aspect)
+
+
+FULL = [("cornell_box", 1920, 1080, 8), ("cornell_mesh", 1920, 1080, 8), ("random_spheres", 1920, 1080, 8),
+        ("mesh_in_box", 1920, 1080, 8), ("backrooms_pool", 1920, 1080, 8), ("flamingo", 1920, 1080, 8),
+        ("many_squares:33:0", 1920, 1080, 8), ("many_squares:64:2", 1920, 1080, 8), ("many_squares:70:5", 1920, 1080, 8)]
+
+
+@pytest.mark.parametrize("name,w,h,spp", FULL)
+def test_filters_never_change_a_pixel(gpu, name, w, h, spp):
+    """1920x1080 x 8 spp = 16.6 M paths x up to 6 bounces per scene and kernel form (all five BASELINE config scenes,
+    the two-light flamingo scene, and square clouds on both sides of the 32 / 64 mask limits)."""
+    host, desc, dev, cam = _scene(gpu, name, w / h)
+    for form, label in ((gpu.FLAG_STREAM_KERNEL, "streaming"), (gpu.FLAG_WAVE_KERNEL, "lane-per-pixel")):
+        a, _ = dev.render(cam, w, h, spp, seed=3, flags=form)
+        b, _ = dev.render(cam, w, h, spp, seed=3, flags=form | gpu.FLAG_EXACT_ONLY)
+        assert np.isfinite(a).all() and a.max() > 0
+        assert np.array_equal(a, b), f"{name} ({label}): filtered vs exact-only: {describe_difference(a, b)}"
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_mesh", 1920, 1080, 8), ("mesh_in_box", 1280, 720, 4), ("backrooms_pool", 640, 360, 2),
+                                          ("flamingo", 480, 270, 2), ("many_squares:64:2", 1920, 1080, 8)])
+def test_kd_walk_selects_the_brute_force_hit(gpu, name, w, h, spp):
+    """The rope walk visits a subset of the triangles; Mesh::intersectOld (Mesh.h:257-277) tests them all.  Same pixels:
+    the walk never skips the closest triangle, on primary, scattered and shadow rays."""
+    host, desc, dev, cam = _scene(gpu, name, w / h)
+    a, _ = dev.render(cam, w, h, spp, seed=5)
+    b, _ = dev.render(cam, w, h, spp, seed=5, flags=gpu.FLAG_STREAM_KERNEL | gpu.FLAG_EXACT_ONLY | gpu.FLAG_MESH_BRUTE)
+    assert a.max() > 0
+    assert np.array_equal(a, b), f"{name}: KD walk vs every triangle: {describe_difference(a, b)}"
+
+
+def test_exact_flags_are_validated(gpu):
+    host, desc, dev, cam = _scene(gpu, "cornell_mesh", 1.0)
+    with pytest.raises(gpu.HrtError, match="EXACT_ONLY"):
+        dev.render(cam, 8, 8, 1, flags=gpu.FLAG_MESH_BRUTE)
+    with pytest.raises(gpu.HrtError, match="two-stream"):
+        dev.render(cam, 8, 8, 1, flags=gpu.FLAG_EXACT_ONLY | gpu.FLAG_DUAL_KERNEL)
