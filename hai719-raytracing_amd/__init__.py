@@ -126,6 +126,7 @@ def host_lib() -> C.CDLL:
         lib.hrt_host_scene_set_kd_params.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         lib.hrt_host_scene_flatten.argtypes = [C.c_void_p, C.c_void_p]
         lib.hrt_host_scene_kd_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.hrt_host_scene_irregular_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.hrt_host_default_camera.argtypes = [C.c_float, C.POINTER(Camera)]
         lib.hrt_host_default_camera.restype = None
         _host = lib
@@ -260,6 +261,16 @@ class HostScene:
         self._check(self._lib.hrt_host_scene_kd_stats(self._h, mesh, out))
         keys = ["inner", "leaves", "empty_leaves", "depth", "leaf_tri_refs", "units"]
         return dict(zip(keys, list(out)))
+
+
+def _irregular_stats(self, mesh: int = 0) -> dict:
+    """Triangles kept out of the SAH tree because the reference's own tree treats them specially (host/ref_tree.h)."""
+    out = (C.c_uint32 * 8)()
+    self._check(self._lib.hrt_host_scene_irregular_stats(self._h, mesh, out))
+    return dict(zip(["out_of_tree", "slivers", "dropped", "pairs", "ref_leaves", "ref_depth", "dead", "entries"], list(out)))
+
+
+HostScene.irregular_stats = _irregular_stats
 
 
 def default_camera(aspect: float) -> Camera:

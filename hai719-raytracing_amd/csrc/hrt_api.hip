@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -361,15 +362,16 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     // ---- meshes: nodelets (refs rebased), leaf-ordered triangle soup, colours
     std::vector<DMesh> meshes;
     std::vector<uint4> units;
-    std::vector<float4> tris, colors;
+    std::vector<float4> tris, colors, exceptions;
     std::vector<uint4> vids;
     for (uint32_t mi = 0; mi < D.n_meshes; ++mi) {
         const hrt_mesh &M = D.meshes[mi];
         if (M.material < 0 || (uint32_t)M.material >= D.n_materials) return fail(HRT_ERR_INVALID, "mesh material out of range");
         for (uint32_t k = 0; k < 3 * M.n_triangles; ++k)
             if (M.indices[k] >= M.n_vertices) return fail(HRT_ERR_INVALID, "mesh vertex index out of range");
-        if (M.n_triangles && (M.kd_root == HRT_KD_NIL || !M.kd_units || !M.n_kd_units))
+        if (M.n_leaf_tris && (M.kd_root == HRT_KD_NIL || !M.kd_units || !M.n_kd_units))
             return fail(HRT_ERR_INVALID, "mesh has triangles but no flattened KD-tree");
+        if (M.n_exceptions && !M.exceptions) return fail(HRT_ERR_INVALID, "mesh exceptions missing");
         DMesh dm;
         std::memset(&dm, 0, sizeof(dm));
         for (int a = 0; a < 3; ++a) {
@@ -387,7 +389,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         };
         // Walk the tree from the root so that only reachable, well-formed nodelets are accepted.
         units.resize(unit_base + M.n_kd_units, make_uint4(0, 0, 0, 0));
-        if (M.n_triangles) {
+        if (M.n_leaf_tris) {
             std::vector<uint32_t> stack{M.kd_root};
             std::vector<uint8_t> seen(M.n_kd_units, 0);
             bool ok = true;
@@ -426,18 +428,45 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
             dm.root = HRT_KD_NIL;
         }
         // triangle soup in leaf order
-        for (uint32_t k = 0; k < M.n_leaf_tris; ++k) {
-            const uint32_t t = M.leaf_tris[k];
-            if (t >= M.n_triangles) return fail(HRT_ERR_INVALID, "leaf triangle id out of range");
+        auto push_triangle = [&](uint32_t t) {
             H3 c[3];
             for (int j = 0; j < 3; ++j) {
                 const float *p = M.positions + 3 * (size_t)M.indices[3 * (size_t)t + j];
                 c[j] = H3{p[0] * HRT_TRIANGLE_SCALING, p[1] * HRT_TRIANGLE_SCALING, p[2] * HRT_TRIANGLE_SCALING};
             }
             fold_triangle(c, t, tris);
+        };
+        for (uint32_t k = 0; k < M.n_leaf_tris; ++k) {
+            const uint32_t t = M.leaf_tris[k];
+            if (t >= M.n_triangles) return fail(HRT_ERR_INVALID, "leaf triangle id out of range");
+            push_triangle(t);
         }
         dm.tri_base = tri_base;
         dm.n_soup = M.n_leaf_tris;
+        // irregular triangles: their rows go behind the leaf-ordered part (no leaf lists them), one slot per triangle
+        dm.exc_base = (uint32_t)(exceptions.size() / 2);
+        dm.n_exc = M.n_exceptions;
+        {
+            std::unordered_map<uint32_t, uint32_t> slots;  // triangle id -> soup slot (each irregular triangle folded once)
+            for (uint32_t k = 0; k < M.n_exceptions; ++k) {
+                const hrt_tri_exception &e = M.exceptions[k];
+                uint32_t word = HRT_EXC_INNER, skip = k + 1u;
+                if (e.triangle == HRT_EXC_INNER) {
+                    if (e.skip <= k || e.skip > M.n_exceptions) return fail(HRT_ERR_INVALID, "exception list: bad skip link");
+                    skip = e.skip;
+                } else {
+                    if (e.triangle >= M.n_triangles) return fail(HRT_ERR_INVALID, "exception triangle id out of range");
+                    auto it = slots.find(e.triangle);
+                    if (it == slots.end()) {
+                        it = slots.emplace(e.triangle, (uint32_t)(tris.size() / HRT_TRI_ROWS)).first;
+                        push_triangle(e.triangle);
+                    }
+                    word = it->second;
+                }
+                exceptions.push_back(make_float4(e.box_min[0], e.box_min[1], e.box_min[2], as_float(word)));
+                exceptions.push_back(make_float4(e.box_max[0], e.box_max[1], e.box_max[2], as_float(skip)));
+            }
+        }
         dm.material = (uint32_t)M.material;
         dm.color_type = HRT_COLOR_NONE;
         if (M.color_type == HRT_COLOR_FACE && M.face_colors) {
@@ -480,6 +509,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     UP(images, images, DImage)
     UP(texels, texels, uint32_t)
     UP(lights, lights, float4)
+    UP(exceptions, exceptions, float4)
 #undef UP
     d.n_spheres = D.n_spheres; d.n_quads = D.n_quads; d.n_meshes = D.n_meshes; d.n_lights = D.n_lights;
     d.n_images = D.n_images;

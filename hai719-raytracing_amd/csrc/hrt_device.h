@@ -14,6 +14,8 @@
 //   materials     6 float4 rows per material, read per lane at the closest hit
 //   meshes        DMesh records (wave-uniform)
 //   kd units      uint4 nodelets (include/hrt.h), refs rebased to the global array
+//   exceptions    irregular triangles (include/hrt.h hrt_tri_exception): {reference leaf box lo, soup slot} {box hi, -}; their
+//                 rows sit behind the mesh's leaf-ordered part of the soup
 //   triangles     leaf-ordered soup, 5 float4 rows: {c0, id} {e1, d00} {e2, d01} {n, D} {d11, denom, -, -}
 //                 (Triangle.h:32-37, 62-75 constants folded on the host in the reference's arithmetic)
 //   colours       float4 per face / per vertex (+ uint4 vertex ids per triangle)
@@ -43,7 +45,8 @@ struct DMesh {
     uint32_t color_base;           // into colours (face) or into vert ids / vertex colours
     uint32_t vcolor_base;
     uint32_t n_soup;               // rows-of-five in this mesh's leaf-ordered soup (straddlers repeated)
-    uint32_t pad1;
+    uint32_t exc_base, n_exc;      // irregular triangles (hrt_tri_exception): entries [exc_base, exc_base + n_exc) of DScene::exceptions
+    uint32_t pad1, pad2, pad3;     // 96 bytes
 };
 
 struct DImage {
@@ -64,6 +67,7 @@ struct DScene {
     const DImage *images;
     const uint32_t *texels;
     const float4 *lights;  // 2 rows: {pos.xyz, radius} {color.xyz, 0}
+    const float4 *exceptions;  // 2 rows per entry: {box lo, soup slot of the triangle} {box hi, 0}
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
     uint32_t n_kd_units;
     int32_t dark_sky, skybox_image;

@@ -255,9 +255,10 @@ __device__ __forceinline__ bool aabb_gate_exact(const B &box, const Ray &ray) {
 // KDTree.cpp:82 gate.  An fp32 slab test with a margin settles the clear cases (each slab distance
 // differs from the reference's by <= 3e-7 |t|); only a ray that grazes the box within the margin, or
 // has a zero direction component, pays for the exact fp64 form.
-template <bool EXACT, class B>
-__device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 inv) {
-    if (EXACT) return aabb_gate_exact(box, ray);
+// The fp32 slab test in front of AABB::intersects: -1 the ray certainly misses the box, +1 it certainly passes, 0 too close
+// to call (within the margin, or a zero direction component).
+template <class B>
+__device__ __forceinline__ int gate_filter(const B &box, const Ray &ray, f3 inv) {
     float g0 = HRT_EPS, g1 = HRT_FLT_MAX, big = 0.f;
     float t0 = (box.lo(0) - ray.o.x) * inv.x, t1 = (box.hi(0) - ray.o.x) * inv.x;
     g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
@@ -267,8 +268,15 @@ __device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 i
     g0 = fmaxf(g0, fminf(t0, t1)); g1 = fminf(g1, fmaxf(t0, t1)); big = fmaxf(big, fmaxf(fabsf(t0), fabsf(t1)));
     const float mg = fmaxf(fabsf(g0), fabsf(g1)) * 2e-6f + 1e-30f;
     const bool finite = big < 1e30f;  // a zero direction component makes a slab distance infinite
-    if (finite && g1 < g0 - mg) return false;
-    if (finite && g1 > g0 + mg) return true;
+    if (finite && g1 < g0 - mg) return -1;
+    if (finite && g1 > g0 + mg) return 1;
+    return 0;
+}
+template <bool EXACT, class B>
+__device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 inv) {
+    if (EXACT) return aabb_gate_exact(box, ray);
+    const int f = gate_filter(box, ray, inv);
+    if (f != 0) return f > 0;
 #ifdef HRT_ABL_NO_EXACT_GATE  // ablation only: timing experiment, not parity-safe
     return true;
 #else
@@ -308,6 +316,34 @@ __device__ __forceinline__ bool tri_test(gf4 tr, const Ray &ray, float &best_t, 
     return true;
 }
 
+// The IRREGULAR triangles of a mesh (include/hrt.h hrt_tri_exception; host/ref_tree.h): triangles the reference's builder
+// drops in part of its tree, and slivers whose barycentric test accepts phantom points.  They are not in the rope tree;
+// each is tested exactly when the reference would test it -- when the ray passes the box of a reference leaf that holds
+// it (KDTree.cpp:32-46 with AABB.h:48-65; EXACT: the fp64 form only, else the fp32 filter in front of it).
+template <bool EXACT, class MP>
+__device__ __forceinline__ bool mesh_exceptions(cscene S, MP M, const Ray &ray, f3 inv, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
+    const uint32_t n = M->n_exc;
+    bool found = false;
+    if (n != 0u) {
+        gf4 ex = (gf4)S->exceptions + 2u * M->exc_base;
+        gf4 tris = (gf4)S->tris;
+        // rows {box lo, soup slot | HRT_EXC_INNER} {box hi, skip}: a bounding hierarchy threaded depth-first (include/hrt.h)
+        for (uint32_t i = 0; i < n;) {
+            const float4 lo = ld(ex, 2u * i), hi = ld(ex, 2u * i + 1u);
+            const uint32_t slot = __float_as_uint(lo.w);
+            GateBox b;
+            b.l[0] = lo.x; b.l[1] = lo.y; b.l[2] = lo.z; b.h[0] = hi.x; b.h[1] = hi.y; b.h[2] = hi.z;
+            ++i;
+            if (slot == HRT_EXC_INNER) {  // bounds of a subtree: only culls (never in the proof builds)
+                if (!EXACT && gate_filter(b, ray, inv) < 0) i = __float_as_uint(hi.w);
+            } else if (mesh_gate_box<EXACT>(b, ray, inv)) {
+                if (tri_test(tris + HRT_TRI_ROWS * slot, ray, best_t, bu, bv)) { best_tri = slot; found = true; }
+            }
+        }
+    }
+    return found;
+}
+
 // HRT_FLAG_MESH_BRUTE (exact builds only): every triangle of the mesh's leaf-ordered soup, no tree -- the device-side
 // statement of Mesh::intersectOld (Mesh.h:257-277) with the leaf's strict `<` (KDTree.cpp:44).  A straddling triangle
 // sits in the soup once per leaf: the repeats give an equal t and lose to the first.  Tests compare this with the rope
@@ -316,8 +352,8 @@ template <class CX>
 __device__ __forceinline__ bool mesh_brute(const CX &cx, cmesh M, const Ray &ray, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
     gf4 tris = (gf4)cx.S->tris;
     const uint32_t first = M->tri_base, cnt = M->n_soup;
-    bool found = false;
     best_t = HRT_FLT_MAX;
+    bool found = mesh_exceptions<true>(cx.S, M, ray, mk(0.f, 0.f, 0.f), best_t, best_tri, bu, bv);
     for (uint32_t k = 0; k < cnt; ++k)
         if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, best_t, bu, bv)) { best_tri = first + k; found = true; }
     return found;
@@ -341,8 +377,8 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
         t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
     }
     best_t = HRT_FLT_MAX;
-    if (!(t_entry <= t_scene_exit)) return false;
-    bool found = false;
+    bool found = mesh_exceptions<CX::exact>(cx.S, M, ray, inv, best_t, best_tri, bu, bv);
+    if (!(t_entry <= t_scene_exit)) return found;
     gu4 g_units = (gu4)cx.S->kd_units;
     gf4 tris = (gf4)cx.S->tris;
     const uint32_t tri_base = M->tri_base;

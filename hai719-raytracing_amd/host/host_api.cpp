@@ -197,6 +197,15 @@ int hrt_host_scene_flatten(hrt_host_scene *s, const hrt_scene_desc **out) {
     }
 }
 
+int hrt_host_scene_irregular_stats(hrt_host_scene *s, uint32_t mi, uint32_t out[8]) {
+    if (!s || !out || !s->flat || mi >= s->flat->ref_analysis.size()) return fail(HRT_ERR_INVALID, "irregular_stats: bad argument");
+    const hrt_host::RefTreeAnalysis &a = s->flat->ref_analysis[mi];
+    uint32_t n = 0;
+    for (uint8_t b : a.irregular) n += b ? 1u : 0u;
+    out[0] = n; out[1] = a.n_slivers; out[2] = a.n_dropped; out[3] = a.n_pairs; out[4] = a.ref_leaves; out[5] = a.ref_depth; out[6] = a.n_dead; out[7] = (uint32_t)a.exceptions.size();
+    return HRT_OK;
+}
+
 int hrt_host_scene_kd_stats(hrt_host_scene *s, uint32_t mi, uint32_t out[6]) {
     if (!s || !out || !s->flat || mi >= s->flat->trees.size()) return fail(HRT_ERR_INVALID, "kd_stats: bad argument");
     const FlatKDTree &t = s->flat->trees[mi];

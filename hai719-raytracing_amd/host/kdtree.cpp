@@ -232,15 +232,17 @@ inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 }  // namespace
 
 FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t *indices,
-                             uint32_t nt, const KDBuildParams &params) {
+                             uint32_t nt, const KDBuildParams &params, const uint8_t *skip) {
     FlatKDTree out;
-    if (nt == 0) return out;
     (void)nv;
-    std::vector<TriRef> refs(nt);
+    std::vector<TriRef> refs;
+    refs.reserve(nt);
     Box root;
     for (int a = 0; a < 3; ++a) { root.lo[a] = INFINITY; root.hi[a] = -INFINITY; }
     for (uint32_t t = 0; t < nt; ++t) {
-        TriRef &r = refs[t];
+        if (skip && skip[t]) continue;
+        refs.emplace_back();
+        TriRef &r = refs.back();
         r.id = t;
         for (int a = 0; a < 3; ++a) { r.b.lo[a] = INFINITY; r.b.hi[a] = -INFINITY; }
         for (int k = 0; k < 3; ++k) {
@@ -255,6 +257,8 @@ FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t
             root.hi[a] = std::max(root.hi[a], r.b.hi[a]);
         }
     }
+    if (refs.empty()) return out;  // no (regular) triangle: no tree
+    nt = (uint32_t)refs.size();
     // Pad the root cell so that hits on the hull are strictly inside it.
     for (int a = 0; a < 3; ++a) {
         float pad = 1e-4f * std::max(1.f, std::max(std::fabs(root.lo[a]), std::fabs(root.hi[a])));

@@ -33,8 +33,9 @@ struct FlatKDTree {
 };
 
 // positions: 3*nv floats ALREADY multiplied by HRT_TRIANGLE_SCALING (the
-// triangles the kernel intersects); indices: 3*nt.
+// triangles the kernel intersects); indices: 3*nt.  skip (nt bytes or NULL): triangles with skip[t] != 0 stay out of the
+// tree (the irregular triangles of ref_tree.h, which the kernel tests through their reference leaf boxes instead).
 FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t *indices,
-                             uint32_t nt, const KDBuildParams &params = KDBuildParams());
+                             uint32_t nt, const KDBuildParams &params = KDBuildParams(), const uint8_t *skip = nullptr);
 
 }  // namespace hrt_host

@@ -1,0 +1,162 @@
+#include "ref_tree.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace hrt_host {
+namespace {
+
+struct Bounds { float lo[3], hi[3]; };
+
+struct Analysis {
+    const float *pos;
+    const uint32_t *idx;
+    std::vector<Bounds> tb;                  // Triangle::getAABB of every triangle (Triangle.h:128-141), unscaled
+    std::vector<uint8_t> dropped;            // lost by some subtree below depth 100
+    std::vector<std::vector<uint32_t>> leaf_tris;
+    std::vector<Bounds> leaf_box;
+    uint32_t depth_reached = 0;
+
+    // KDTree::buildTree, KDTree.cpp:100-151.  `tris` by value semantics of the reference's vectors; box = the node's AABB.
+    void partition(const std::vector<uint32_t> &tris, const Bounds &box, unsigned depth) {
+        if (tris.empty()) return;
+        if (depth > 100u) {                  // KDTREE_MAX_DEPTH: the subtree is not built, its triangles are lost HERE
+            for (uint32_t t : tris) dropped[t] = 1;
+            return;
+        }
+        depth_reached = std::max(depth_reached, depth);
+        auto leaf = [&]() { leaf_tris.push_back(tris); leaf_box.push_back(box); };
+        if (tris.size() <= 40u) { leaf(); return; }   // KDTREE_TRIANGLES_PER_LEAF
+        // cut(), KDTree.cpp:87-98: median of the triangles' lower bounds on axis depth % 3, plus EPSILON (a double), as float
+        const int axis = (int)(depth % 3u);
+        std::vector<float> mins(tris.size());
+        for (size_t i = 0; i < tris.size(); ++i) mins[i] = tb[tris[i]].lo[axis];
+        std::sort(mins.begin(), mins.end());
+        const float position = (float)((double)mins[mins.size() / 2] + HRT_EPSILON);
+        std::vector<uint32_t> left, right;
+        for (uint32_t t : tris) {            // :129-140, comparisons in double as written
+            if ((double)tb[t].hi[axis] <= (double)position - HRT_EPSILON) left.push_back(t);
+            else if ((double)tb[t].lo[axis] >= (double)position + HRT_EPSILON) right.push_back(t);
+            else { left.push_back(t); right.push_back(t); }
+        }
+        if (left.size() == right.size()) { leaf(); return; }   // :143-146
+        Bounds lb = box, rb = box;           // AABB::split, AABB.h:67-75
+        lb.hi[axis] = position;
+        rb.lo[axis] = position;
+        partition(left, lb, depth + 1u);
+        partition(right, rb, depth + 1u);
+    }
+};
+
+}  // namespace
+
+RefTreeAnalysis analyse_reference_tree(const float *positions, uint32_t nv, const uint32_t *indices, uint32_t nt,
+                                       const float aabb_min[3], const float aabb_max[3]) {
+    (void)nv;
+    RefTreeAnalysis out;
+    out.irregular.assign(nt, 0);
+    if (nt == 0) return out;
+    Analysis A;
+    A.pos = positions;
+    A.idx = indices;
+    A.tb.resize(nt);
+    A.dropped.assign(nt, 0);
+    for (uint32_t t = 0; t < nt; ++t) {
+        Bounds &b = A.tb[t];
+        for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+        for (int k = 0; k < 3; ++k) {
+            const float *p = positions + 3 * (size_t)indices[3 * (size_t)t + k];
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], p[a]); b.hi[a] = std::max(b.hi[a], p[a]); }
+        }
+    }
+    std::vector<uint32_t> all(nt);
+    for (uint32_t t = 0; t < nt; ++t) all[t] = t;
+    Bounds root;
+    for (int a = 0; a < 3; ++a) { root.lo[a] = aabb_min[a]; root.hi[a] = aabb_max[a]; }
+    A.partition(all, root, 0u);
+    out.ref_leaves = (uint32_t)A.leaf_box.size();
+    out.ref_depth = A.depth_reached;
+
+    // Dead triangles: Triangle's constructor (Triangle.h:32-37) normalises cross(c1 - c0, c2 - c0) by its length; a zero
+    // length makes the normal NaN and every test of getIntersection false -- such a triangle is never hit and is left out.
+    // Slivers: the barycentric solve of Triangle.h:62-75 has condition ~ 1 / sin^2(angle at c0); in fp32 it returns noise
+    // once sin^2 <~ 1e-6.  Everything below 1e-4 (an angle under 0.6 degrees) is treated as irregular -- two orders of
+    // margin; a well-shaped triangle accepts points at most ~1e-6 edge lengths outside itself.
+    // Both evaluated on the scaled vertices in fp32, like the constants the kernel folds (hrt_api.hip fold_triangle).
+    std::vector<uint8_t> dead(nt, 0);
+    for (uint32_t t = 0; t < nt; ++t) {
+        float c[3][3];
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) c[k][a] = positions[3 * (size_t)indices[3 * (size_t)t + k] + a] * HRT_TRIANGLE_SCALING;
+        float e1[3], e2[3];
+        for (int a = 0; a < 3; ++a) { e1[a] = c[1][a] - c[0][a]; e2[a] = c[2][a] - c[0][a]; }
+        const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+        const float norm = (float)std::sqrt((double)(nx * nx + ny * ny + nz * nz));
+        if (!(norm > 0.f)) {  // 0 or NaN: n / norm is NaN
+            dead[t] = 1; out.irregular[t] = 1; ++out.n_dead;
+            continue;
+        }
+        const float d00 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+        const float d01 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+        const float d11 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+        const float denom = d00 * d11 - d01 * d01;
+        const bool sliver = !(denom >= 1e-4f * (d00 * d11));
+        if (sliver) { out.irregular[t] = 1; ++out.n_slivers; }
+        if (A.dropped[t]) { out.irregular[t] = 1; ++out.n_dropped; }
+    }
+    // The reference leaves that hold each live irregular triangle.  One that no leaf holds is never hit: no entry.
+    std::vector<hrt_tri_exception> pairs;
+    for (size_t l = 0; l < A.leaf_box.size(); ++l)
+        for (uint32_t t : A.leaf_tris[l])
+            if (out.irregular[t] && !dead[t]) {
+                hrt_tri_exception e;
+                e.triangle = t;
+                e.skip = 0;
+                for (int a = 0; a < 3; ++a) { e.box_min[a] = A.leaf_box[l].lo[a]; e.box_max[a] = A.leaf_box[l].hi[a]; }
+                pairs.push_back(e);
+            }
+    out.n_pairs = (uint32_t)pairs.size();
+    // Bounding hierarchy over the pairs, emitted depth-first with skip links (median split of the box centres on the
+    // widest axis).  Inner boxes are padded: they only cull, the leaf boxes decide.
+    struct Emit {
+        std::vector<hrt_tri_exception> &src, &dst;
+        void run(size_t lo, size_t hi) {
+            if (hi - lo == 1) { dst.push_back(src[lo]); dst.back().skip = (uint32_t)dst.size(); return; }
+            float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+            float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t i = lo; i < hi; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    bmin[a] = std::min(bmin[a], src[i].box_min[a]); bmax[a] = std::max(bmax[a], src[i].box_max[a]);
+                    const float c = 0.5f * (src[i].box_min[a] + src[i].box_max[a]);
+                    cmin[a] = std::min(cmin[a], c); cmax[a] = std::max(cmax[a], c);
+                }
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+            const size_t mid = lo + (hi - lo) / 2;
+            std::nth_element(src.begin() + lo, src.begin() + mid, src.begin() + hi, [axis](const hrt_tri_exception &x, const hrt_tri_exception &y) {
+                const float cx = x.box_min[axis] + x.box_max[axis], cy = y.box_min[axis] + y.box_max[axis];
+                return cx < cy || (cx == cy && x.triangle < y.triangle);
+            });
+            const size_t self = dst.size();
+            hrt_tri_exception n;
+            n.triangle = HRT_EXC_INNER;
+            n.skip = 0;
+            for (int a = 0; a < 3; ++a) {
+                const float pad = 1e-4f * std::max(1.f, std::max(std::fabs(bmin[a]), std::fabs(bmax[a])));
+                n.box_min[a] = bmin[a] - pad; n.box_max[a] = bmax[a] + pad;
+            }
+            dst.push_back(n);
+            run(lo, mid);
+            run(mid, hi);
+            dst[self].skip = (uint32_t)dst.size();
+        }
+    };
+    if (!pairs.empty()) {
+        Emit em{pairs, out.exceptions};
+        em.run(0, pairs.size());
+    }
+    return out;
+}
+
+}  // namespace hrt_host

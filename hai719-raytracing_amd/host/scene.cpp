@@ -417,7 +417,7 @@ std::unique_ptr<FlatScene> Scene::flatten() const {
     }
     const size_t nm = meshes.size();
     f.mesh_positions.resize(nm); f.mesh_vcolors.resize(nm); f.mesh_fcolors.resize(nm);
-    f.mesh_indices.resize(nm); f.trees.resize(nm);
+    f.mesh_indices.resize(nm); f.trees.resize(nm); f.ref_analysis.resize(nm);
     for (size_t mi = 0; mi < nm; ++mi) {
         const Mesh &m = meshes[mi];
         hrt_mesh o;
@@ -446,8 +446,13 @@ std::unique_ptr<FlatScene> Scene::flatten() const {
         // Mesh::computeKDTree (Mesh.cpp:107-110): recompute the box, then build.
         Mesh boxed = m;
         boxed.computeAABB();
+        const float amin[3] = {boxed.aabb.p0[0], boxed.aabb.p0[1], boxed.aabb.p0[2]}, amax[3] = {boxed.aabb.p1[0], boxed.aabb.p1[1], boxed.aabb.p1[2]};
+        // What the reference's own tree does to this mesh that no other tree would reproduce (ref_tree.h): dropped
+        // triangles and slivers stay out of the SAH tree and travel as (triangle, reference leaf box) exceptions.
+        f.ref_analysis[mi] = analyse_reference_tree(pos.data(), (uint32_t)m.vertices.size(), idx.data(), (uint32_t)m.triangles.size(),
+                                                    amin, amax);
         f.trees[mi] = build_flat_kdtree(scaled.data(), (uint32_t)m.vertices.size(), idx.data(),
-                                        (uint32_t)m.triangles.size(), kd_params);
+                                        (uint32_t)m.triangles.size(), kd_params, f.ref_analysis[mi].irregular.data());
         o.n_vertices = (uint32_t)m.vertices.size();
         o.n_triangles = (uint32_t)m.triangles.size();
         o.positions = pos.data();
@@ -464,6 +469,8 @@ std::unique_ptr<FlatScene> Scene::flatten() const {
         o.kd_units = f.trees[mi].units.data();
         o.n_leaf_tris = (uint32_t)f.trees[mi].leaf_tris.size();
         o.leaf_tris = f.trees[mi].leaf_tris.data();
+        o.n_exceptions = (uint32_t)f.ref_analysis[mi].exceptions.size();
+        o.exceptions = f.ref_analysis[mi].exceptions.empty() ? nullptr : f.ref_analysis[mi].exceptions.data();
         f.meshes.push_back(o);
     }
     for (const Light &l : lights) {

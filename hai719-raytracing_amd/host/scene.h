@@ -14,6 +14,7 @@
 #include "../../include/hrt.h"
 #include "geom.h"
 #include "kdtree.h"
+#include "ref_tree.h"
 
 namespace hrt_host {
 
@@ -30,6 +31,7 @@ struct FlatScene {
     std::vector<std::vector<float>> mesh_positions, mesh_vcolors, mesh_fcolors;
     std::vector<std::vector<uint32_t>> mesh_indices;
     std::vector<FlatKDTree> trees;
+    std::vector<RefTreeAnalysis> ref_analysis;  // irregular triangles per mesh (ref_tree.h)
 };
 
 class Scene {

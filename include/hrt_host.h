@@ -63,6 +63,12 @@ int hrt_host_scene_flatten(hrt_host_scene *s, const hrt_scene_desc **out);
 /* out[0..5] = inner nodes, leaves, empty leaves, depth, leaf triangle refs, 16-byte units */
 int hrt_host_scene_kd_stats(hrt_host_scene *s, uint32_t mesh_index, uint32_t out[6]);
 
+/* Irregular triangles of a mesh after flatten (hrt.h hrt_tri_exception, host/ref_tree.h):
+ * out[0..7] = triangles kept out of the tree, of them slivers, of them dropped by the reference's builder, (triangle,
+ * leaf box) pairs, leaves and depth of the reference's partition, dead (zero-area, never hit) triangles, entries of
+ * the threaded exception list (pairs + bounding entries). */
+int hrt_host_scene_irregular_stats(hrt_host_scene *s, uint32_t mesh_index, uint32_t out[8]);
+
 void hrt_host_default_camera(float aspect_ratio, hrt_camera *out);
 
 /* PPM loader probe (imageLoader.cpp:21-103): size and FNV-1a hash of the RGB bytes of `path`. */

@@ -343,6 +343,13 @@ inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 TriHit rope_tree_intersect(const OMesh &m, const Ray &ray, Counters *cnt) {
     TriHit best;
     const hrt_mesh &s = *m.src;
+    for (uint32_t k = 0; k < s.n_exceptions; ++k) {  // irregular triangles: through their reference leaf boxes (include/hrt.h)
+        const hrt_tri_exception &e = s.exceptions[k];
+        if (e.triangle == HRT_EXC_INNER) continue;  // a bounding entry of the threaded list: culls only
+        if (!aabb_intersects(e.box_min, e.box_max, ray)) continue;
+        TriHit h = leaf_triangle(m, e.triangle, ray, cnt);
+        if (h.t < best.t) { best = h; best.tIndex = e.triangle; }
+    }
     if (s.kd_root == HRT_KD_NIL || s.n_kd_units == 0) return best;
     uint32_t ref = s.kd_root;
     float t_entry = 0.f;

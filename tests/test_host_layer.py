@@ -28,7 +28,7 @@ class MeshDesc(C.Structure):  # hrt_mesh (include/hrt.h)
                 ("color_type", C.c_int32), ("vert_colors", C.c_void_p), ("face_colors", C.c_void_p),
                 ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("material", C.c_int32), ("kd_root", C.c_uint32),
                 ("kd_min", C.c_float * 3), ("kd_max", C.c_float * 3), ("n_kd_units", C.c_uint32), ("kd_units", C.c_void_p),
-                ("n_leaf_tris", C.c_uint32), ("leaf_tris", C.c_void_p)]
+                ("n_leaf_tris", C.c_uint32), ("leaf_tris", C.c_void_p), ("n_exceptions", C.c_uint32), ("exceptions", C.c_void_p)]
 
 
 def mesh_box(desc, m):
@@ -105,26 +105,58 @@ def test_random_spheres_scene_is_seeded(hrt, oracle):
     assert np.array_equal(imgs[0], imgs[1]) and not np.array_equal(imgs[0], imgs[2])
 
 
-@pytest.mark.parametrize("name", ["cornell_mesh", "mesh_in_box"])
-def test_flattened_rope_tree_equals_brute_force_and_reference_tree(hrt, oracle, name):
-    """Closest hit over a mesh: the product's flattened rope KD-tree (walked on the CPU by the oracle with
-    the kernel's algorithm), brute force (Mesh::intersectOld) and the reference-shaped tree agree exactly."""
+def _mesh_rays(rng, lo, hi, n):
+    """Rays aimed at the mesh box from around it, half of them starting inside, six axis-parallel ones."""
+    o = rng.uniform(-1, 1, (n, 3)) * (hi - lo) * 1.5 + (lo + hi) / 2
+    d = rng.uniform(0, 1, (n, 3)) * (hi - lo) + lo - o
+    o[: n // 2] = rng.uniform(0, 1, (n // 2, 3)) * (hi - lo) + lo
+    d[: n // 2] = rng.normal(size=(n // 2, 3))
+    d[:6] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]
+    return np.concatenate([o, d, np.zeros((n, 1))], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["cornell_mesh", "mesh_in_box", "backrooms_pool"])
+def test_flattened_rope_tree_equals_the_reference_tree(hrt, oracle, name):
+    """Closest hit over a mesh: the product's flattened rope KD-tree + exception list (walked on the CPU by the oracle
+    with the kernel's algorithm) against the reference-shaped tree (KDTree.cpp restated), exactly, on every config mesh.
+    Brute force (Mesh::intersectOld) agrees too where the mesh has no slivers; where it has (triceratops: two collinear
+    triangles) it finds phantom hits that the reference's tree -- and therefore the product -- only finds through the
+    sliver's own leaf boxes (host/ref_tree.h)."""
     host = hrt.HostScene().setup(name, 16 / 9, 1)
     desc = host.flatten()
     rng = np.random.default_rng(5)
-    n = 6000
-    o = rng.uniform(-3, 3, (n, 3))
-    d = (rng.uniform(-1.2, 1.2, (n, 3)) + np.array([0, -1, -0.5])) - o
-    o[: n // 2] = rng.uniform(-1, 1, (n // 2, 3)) * np.array([0.8, 1.0, 0.8]) + np.array([0, -1, -0.5])
-    d[: n // 2] = rng.normal(size=(n // 2, 3))
-    d[:6] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]  # axis-parallel rays
-    rays = np.concatenate([o, d, np.zeros((n, 1))], 1).astype(np.float32)
-    brute = oracle.mesh_query(desc, 0, oracle.MESH_BRUTE, rays)
-    ref = oracle.mesh_query(desc, 0, oracle.MESH_REF_TREE, rays)
-    rope = oracle.mesh_query(desc, 0, oracle.MESH_ROPE_TREE, rays)
-    assert brute[:, 0].sum() > 300
-    assert np.array_equal(brute, ref)
-    assert np.array_equal(brute, rope)
+    for m in range(counts(desc)["meshes"]):
+        lo, hi = mesh_box(desc, m)
+        rays = _mesh_rays(rng, lo, hi, 6000)
+        ref = oracle.mesh_query(desc, m, oracle.MESH_REF_TREE, rays)
+        rope = oracle.mesh_query(desc, m, oracle.MESH_ROPE_TREE, rays)
+        assert ref[:, 0].sum() > 100
+        assert np.array_equal(ref, rope), (name, m, int((ref != rope).any(axis=1).sum()))
+        st = host.irregular_stats(m)
+        if st["slivers"] == 0 and st["dropped"] == 0:
+            assert np.array_equal(ref, oracle.mesh_query(desc, m, oracle.MESH_BRUTE, rays)), (name, m)
+
+
+def test_irregular_triangles_are_found_and_kept_out_of_the_tree(hrt, oracle):
+    """host/ref_tree.h on known meshes: flamingo_lowpoly has 64 zero-area triangles (dead: never hit, left out),
+    triceratops two collinear slivers (exceptions with their reference leaf boxes), the magic staff of `raccoon` and the
+    pond lose triangles below depth 100 of the reference's builder (N11)."""
+    host = hrt.HostScene().setup("cornell_mesh", 16 / 9, 1); host.flatten()
+    st = host.irregular_stats(0)
+    assert (st["dead"], st["slivers"], st["dropped"], st["entries"]) == (64, 0, 0, 0)
+    host = hrt.HostScene().setup("mesh_in_box", 16 / 9, 1); desc = host.flatten()
+    st = host.irregular_stats(0)
+    assert (st["dead"], st["slivers"], st["dropped"], st["pairs"]) == (0, 2, 0, 2) and st["entries"] == 3
+    d = C.cast(desc, C.POINTER(SceneDesc)).contents
+    m = C.cast(d.meshes, C.POINTER(MeshDesc))[0]
+    leaf = np.ctypeslib.as_array(C.cast(m.leaf_tris, C.POINTER(C.c_uint32)), shape=(m.n_leaf_tris,))
+    exc = np.ctypeslib.as_array(C.cast(m.exceptions, C.POINTER(C.c_uint32)), shape=(m.n_exceptions, 8))
+    tri = exc[exc[:, 0] != 0xFFFFFFFF][:, 0]
+    assert len(tri) == 2 and not np.isin(tri, leaf).any()           # irregular triangles are not in any leaf
+    assert len(np.unique(leaf)) == m.n_triangles - 2                # everything else is
+    assert exc[0, 0] == 0xFFFFFFFF and exc[0, 1] == 3               # one bounding entry over the two pairs
+    host = hrt.HostScene().setup("raccoon", 16 / 9, 1); host.flatten()
+    assert host.irregular_stats(1)["dropped"] > 0 and host.irregular_stats(1)["ref_depth"] == 100
 
 
 def test_kd_builder_parameters_and_degenerate_meshes(hrt, oracle):
@@ -233,9 +265,9 @@ DEMO_COUNTS = {  # scene: (spheres, quads, meshes, lights, dark_sky, images) as 
 @pytest.mark.parametrize("name", list(DEMO_COUNTS))
 def test_demo_scenes_build_and_their_meshes_walk_exactly(hrt, oracle, name):
     """the reference's demo scenes outside BASELINE's configs.  Object counts as the reference's
-    set-up code creates them; for every mesh the flattened rope tree and brute force return the same closest
-    triangle on rays aimed at the mesh (pond / staff: the reference's own builder drops a triangle, N11, so the
-    reference-shaped tree is not the yardstick there)."""
+    set-up code creates them; for every mesh the flattened rope tree + exception list and the reference-shaped tree
+    return the same closest triangle on rays aimed at the mesh -- including the pond and the magic staff, where the
+    reference's own builder drops triangles below depth 100 (N11) and leaves holes that the product reproduces."""
     host = hrt.HostScene().setup(name, 16 / 9, 1)
     desc = host.flatten()
     c = counts(desc)
@@ -244,16 +276,11 @@ def test_demo_scenes_build_and_their_meshes_walk_exactly(hrt, oracle, name):
     rng = np.random.default_rng(11)
     for m in range(c["meshes"]):
         lo, hi = mesh_box(desc, m)
-        n = 3000
-        o = rng.uniform(-1, 1, (n, 3)) * (hi - lo) * 1.5 + (lo + hi) / 2
-        target = rng.uniform(0, 1, (n, 3)) * (hi - lo) + lo
-        d = target - o
-        d[:6] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]
-        rays = np.concatenate([o, d, np.zeros((n, 1))], 1).astype(np.float32)
-        brute = oracle.mesh_query(desc, m, oracle.MESH_BRUTE, rays)
+        rays = _mesh_rays(rng, lo, hi, 3000)
+        ref = oracle.mesh_query(desc, m, oracle.MESH_REF_TREE, rays)
         rope = oracle.mesh_query(desc, m, oracle.MESH_ROPE_TREE, rays)
-        assert brute[:, 0].sum() > 200, (name, m)
-        assert np.array_equal(brute, rope), (name, m)
+        assert ref[:, 0].sum() > 200, (name, m)
+        assert np.array_equal(ref, rope), (name, m, int((ref != rope).any(axis=1).sum()))
     img = oracle.OracleScene(desc).render(cam, 32, 18, 1, seed=1, threads=0)
     assert np.isfinite(img).all() and img.max() > 0
 
