@@ -155,6 +155,7 @@ def device_lib() -> C.CDLL:
         lib.hrt_assemble_frame.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p]
         lib.hrt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.hrt_check_last_launch.argtypes = [C.c_void_p]
         lib.hrt_kernel_info.argtypes = [C.POINTER(Stats)]
         lib.hrt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.hrt_render_accumulate.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -336,6 +337,10 @@ class DeviceScene:
         """hrt_render_accumulate: add samples [first_sample, first_sample + n_samples) to the running sums (asynchronous)."""
         self._check(self._lib.hrt_render_accumulate(self._h, C.byref(cam), w, h, first_sample, n_samples, seed, flags, rank,
                                                     world, C.c_void_p(d_sum_tiles_ptr), C.c_void_p(stream_ptr)))
+
+    def check_last_launch(self):
+        """hrt_check_last_launch: waits for the last launch; raises if the trace kernel gave up (incomplete tiles)."""
+        self._check(self._lib.hrt_check_last_launch(self._h))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_double()

@@ -185,6 +185,7 @@ struct hrt_scene {
     float *d_tiles = nullptr, *d_frame = nullptr;
     size_t tiles_cap = 0, frame_cap = 0;
     uint32_t last_grid = 0, last_waves = 0, last_lds = 0;
+    hipStream_t last_stream = nullptr;  // stream of the previous launch on this scene
 };
 
 extern "C" {
@@ -403,6 +404,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 const hrt_kdunit *u = M.kd_units + idx;
                 if (ref & HRT_KD_LEAF) {
                     if ((uint64_t)u[0].w[3] + u[1].w[3] > M.n_leaf_tris) { ok = false; break; }
+                    if (u[1].w[3] >= 0xFFFFu) return fail(HRT_ERR_INVALID, "KD leaf with 65535 or more triangles (the resumable walk keeps a 16-bit leaf cursor): build the tree with a smaller leaf_max");
                     s->max_leaf = std::max(s->max_leaf, u[1].w[3]);
                     units[unit_base + idx] = make_uint4(u[0].w[0], u[0].w[1], u[0].w[2], u[0].w[3]);
                     units[unit_base + idx + 1] = make_uint4(u[1].w[0], u[1].w[1], u[1].w[2], u[1].w[3]);
@@ -617,6 +619,7 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
     if (!g_rt.ready) return fail(HRT_ERR_STATE, "render: call hrt_init first");
     if (!w || !h || !spp) return fail(HRT_ERR_INVALID, "render: w, h and spp must be positive");
     if ((uint64_t)w * h > 0x7fffffffull) return fail(HRT_ERR_INVALID, "render: image too large");
+    if (w > 65535u || h > 65535u) return fail(HRT_ERR_INVALID, "render: w and h must be below 65536 (tile origins are packed in 16 + 16 bits)");
     if (!world || rank >= world) return fail(HRT_ERR_INVALID, "render: bad rank/world");
     R.scene = s->d_scene;
     R.cam = s->d_cam;
@@ -671,7 +674,7 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     if ((flags & HRT_FLAG_MESH_BRUTE) && !exact) return fail(HRT_ERR_INVALID, "render: HRT_FLAG_MESH_BRUTE needs HRT_FLAG_EXACT_ONLY");
     if (exact && (flags & HRT_FLAG_DUAL_KERNEL)) return fail(HRT_ERR_INVALID, "render: no exact-only build of the two-stream kernel");
     const bool dual_kernel = !exact && !stream_kernel && (g_rt.use_dual || (flags & HRT_FLAG_DUAL_KERNEL)) && s->d.n_meshes > 0u &&
-                             s->max_leaf < 0xFFFFu && !(flags & HRT_FLAG_WAVE_KERNEL);
+                             !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
         const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4);
@@ -731,6 +734,10 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     s->last_grid = grid;
     s->last_lds = lds_bytes;
     s->last_waves = stream_kernel ? grid * (HRT_SP_WG / 64) : grid * (HRT_WG / 64u);
+    // One hrt_scene carries ONE launch at a time (work-queue head, stamps, path pool, camera block).  Launches on one
+    // stream are ordered by the stream; a launch on another stream first waits for the previous one.
+    if (s->timed && s->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->ev1, 0));
+    s->last_stream = stream;
     HIP_TRY(hipMemsetAsync(s->tile_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(s->stamps, 0, 16 * sizeof(unsigned long long), stream));  // [15] = give-up code of the streaming kernel
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -840,14 +847,22 @@ int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, uns
     return HRT_OK;
 }
 
+int hrt_check_last_launch(hrt_scene *s) {
+    if (!s) return fail(HRT_ERR_INVALID, "hrt_check_last_launch: NULL scene");
+    if (!s->timed) return HRT_OK;
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    unsigned long long gave_up = 0;
+    HIP_TRY(hipMemcpy(&gave_up, s->stamps + 15, sizeof(gave_up), hipMemcpyDeviceToHost));
+    if (gave_up) return fail(HRT_ERR_DEVICE, "trace kernel gave up (scheduler cycle bound exceeded): the frame of the last launch is incomplete");
+    return HRT_OK;
+}
+
 int hrt_last_kernel_ms(hrt_scene *s, double *ms) {
     if (!s || !ms) return fail(HRT_ERR_INVALID, "hrt_last_kernel_ms: NULL argument");
     if (!s->timed) { *ms = 0.0; return HRT_OK; }
-    HIP_TRY(hipEventSynchronize(s->ev1));
     {
-        unsigned long long gave_up = 0;
-        HIP_TRY(hipMemcpy(&gave_up, s->stamps + 15, sizeof(gave_up), hipMemcpyDeviceToHost));
-        if (gave_up) return fail(HRT_ERR_DEVICE, "trace kernel gave up: scheduler cycle bound exceeded");
+        const int rc = hrt_check_last_launch(s);
+        if (rc != HRT_OK) return rc;
     }
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, s->ev0, s->ev1));
@@ -907,6 +922,8 @@ int hrt_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint
     rc = hrt_assemble_frame(s->d_tiles, (uint32_t)tiles, w, h, 1, s->d_frame, nullptr);
     if (rc != HRT_OK) return rc;
     HIP_TRY(hipMemcpy(out_rgb, s->d_frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost));
+    rc = hrt_check_last_launch(s);  // never hand back a frame the kernel did not finish
+    if (rc != HRT_OK) return rc;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         double ms = 0.0;

@@ -45,7 +45,7 @@ namespace hrtk {
 struct Walk {
     uint32_t ref;      // next nodelet, HRT_KD_NIL = no walk in progress
     float t_entry;     // entry distance of the current cell
-    uint32_t kk;       // trips so far << 16 | triangle cursor of the current leaf (0xFFFF: leaf not entered yet)
+    uint32_t kk;       // cells crossed so far << 16 | triangle cursor of the current leaf (0xFFFF: leaf not entered yet)
     float best_t;      // closest triangle of THIS mesh so far (KDTree.cpp:44), merged into the hit when the walk ends
     uint32_t best_tri;
     float bu, bv;
@@ -190,10 +190,10 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
                     const uint32_t sel = face & 3u;
                     ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
                     k = 0xFFFFu;
+                    if (++count >= HRT_WALK_CELLS) ref = HRT_KD_NIL;  // mesh_traverse's bound on the cells of one walk
                 }
             }
         }
-        if (++count >= 8192u) ref = HRT_KD_NIL;  // mesh_traverse's bound on the whole walk
     }
     w.ref = ref; w.t_entry = t_entry; w.kk = (count << 16) | k;
     return ref == HRT_KD_NIL;

@@ -388,10 +388,11 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
     uint32_t ref = M->root;
     uint32_t k = 0, cnt = ~0u, first = 0;  // triangle cursor of the current leaf; cnt == ~0: leaf not entered yet
     f3 p = ray.o + t_entry * ray.d;
-#ifndef HRT_ABL_GUARD
-#define HRT_ABL_GUARD 8192  // smaller values: ablation only (cuts long walks short, not parity-safe)
-#endif
-    for (int guard = 0; guard < HRT_ABL_GUARD && ref != HRT_KD_NIL; ++guard) {  // bounded: every wave leaves
+#ifndef HRT_WALK_CELLS
+#define HRT_WALK_CELLS 8192  // cells one walk may cross: far beyond any real walk (a ray crosses O(depth * n^(1/3)) cells); it only
+#endif                       // stops a walk that rounding sends back and forth between two cells.  Triangle tests are NOT counted:
+                             // a leaf of any size is tested to its end (smaller values: ablation only, not parity-safe)
+    for (uint32_t cells = 0; cells < HRT_WALK_CELLS && ref != HRT_KD_NIL;) {  // bounded: every wave leaves
 #pragma unroll
         for (int lvl = 0; lvl < 2; ++lvl) {
             if (!(ref & HRT_KD_LEAF)) {
@@ -432,6 +433,7 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
                     const uint32_t sel = face & 3u;
                     ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
                     cnt = ~0u;
+                    ++cells;
                 }
             }
         }

@@ -55,6 +55,9 @@
 #define HRT_SP_TRIPS 6     // KD-walk trips per T visit (A/B 1080p@256, ms Cornell+mesh / mesh_in_box / pool: 6 -> 264 / 301 / 649, 8 -> 264 / 305 / 659, 12 -> 265 / 311 / 686);
                            // an unfinished walk goes back to the T queue with its state
 #endif
+#ifndef HRT_SP_CYCLE_BOUND
+#define HRT_SP_CYCLE_BOUND (1u << 16)  // scheduler cycles one sample chunk of one work unit may take before the workgroup gives up
+#endif                                 // (a test build sets it to 3 to exercise the give-up path: Makefile, libhrt_var_bound.so)
 #define HRT_SP_NQ 8        // queues: T0 T1 A0 A1 B0 B1 F0 F1 (A: sphere hits from the front, quad hits from the back;
                            // B: misses from the front, mesh hits from the back -- a path sits in exactly one place)
 
@@ -74,6 +77,7 @@ struct SpCtl {           // control block in LDS (20 dwords)
     uint32_t cursor;         // chunk cursor of the running cycle
     uint32_t ngen, gen_n0, paths_left;
     uint32_t done, tile, parity, cycles;
+    uint32_t gave_up;        // the cycle bound tripped: the whole workgroup leaves the kernel
 };
 
 static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
@@ -186,7 +190,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         C.cT[0] = C.cT[1] = 0;
         for (int k = 0; k < 4; ++k) C.cK[k][0] = C.cK[k][1] = 0;
         C.cF[0] = HRT_SP_POOL; C.cF[1] = 0;
-        C.parity = 0; C.cycles = 0; C.done = 0;
+        C.parity = 0; C.cycles = 0; C.done = 0; C.gave_up = 0;
     }
     for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 3, 0)[i] = (uint16_t)i;  // every slot free
     const bool has_mesh = cx.S->n_meshes != 0u;
@@ -241,9 +245,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     for (int k = 0; k < 4; ++k) { C.cK[k][par ^ 1u] = 0; waiting += C.cK[k][par]; }
                     C.cF[par ^ 1u] = C.cF[par] - ngen;  // the unused free slots carry over, S appends after them
                     C.done = (ngen == 0u && waiting == 0u) ? 1u : 0u;
-                    if (++C.cycles > (1u << 16)) {  // bounded: a scheduling bug must not spin the GPU; the host reports it
-                        if (R.stamps) R.stamps[15] = 0xDEADull;
+                    if (++C.cycles > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
+                        // The frame is lost: flag it for the host (hrt_check_last_launch / hrt_render return HRT_ERR_DEVICE)
+                        // and take the whole workgroup out of the kernel -- its queues and pool hold paths in flight, so
+                        // it must not start another unit from that state.  The other workgroups finish their tiles.
+                        if (R.stamps) __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         C.done = 1u;
+                        C.gave_up = 1u;
                     }
                 }
                 __syncthreads();
@@ -406,19 +414,14 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 __syncthreads();
                 if (tid == 0) { C.paths_left -= ngen; C.gen_n0 += ngen; C.parity = parity ^ 1u; }
             }
+            if (SP_UNI(C.gave_up)) return;  // uniform: written by thread 0 before the barrier every thread passed to get here
             // the chunk has drained: fold its samples into the pixel sums in sample order (main.cpp:193)
             __syncthreads();
-#ifdef HRT_SP_FOLD_ATOMIC
-            for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {  // i = pixel-of-unit * 3 + channel
-                float acc = L.run[i];
-                for (uint32_t s = 0; s < ns; ++s)
-                    acc += __hip_atomic_load(scratch + (size_t)s * (upix * 3u) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                L.run[i] = acc;
-            }
-#else
-            // One agent-scope acquire drops this CU's L1 lines (an earlier unit's fold may have left stale copies of
-            // the scratch other waves have since overwritten); the loads below are then plain and pipeline freely.
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // Plain loads: the scratch was written by waves of THIS workgroup (one CU), every one of which passed the
+            // barrier above after its stores (s_waitcnt vmcnt(0) + s_barrier); a CU's vector L1 is coherent with that CU's
+            // own stores (it is only other CUs' stores it never sees), which is also what the path pool's plain loads and
+            // stores rely on.  (Round 1 put an agent-scope acquire here "against stale L1 lines"; an A/B without it is
+            // bit-identical on every kernel-form test at 1080p -- the hazard does not exist within one workgroup.)
             for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {  // i = pixel-of-unit * 3 + channel
                 float acc = L.run[i];
                 const float *col = scratch + i;
@@ -434,7 +437,6 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 for (; s < ns; ++s) acc += col[(size_t)s * stride];
                 L.run[i] = acc;
             }
-#endif
         }
         __syncthreads();
         for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {

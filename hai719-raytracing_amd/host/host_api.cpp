@@ -126,9 +126,36 @@ int hrt_host_scene_add_quad(hrt_host_scene *s, const float bl[3], const float r[
     return HRT_OK;
 }
 
+int hrt_host_scene_add_quad_ex(hrt_host_scene *s, const float v0[3], const float v1[3], const float v2[3], const float v3[3],
+                               const float tangent[3], const float bitangent[3], const hrt_material *m) {
+    if (!s || !v0 || !v1 || !v2 || !v3 || !tangent || !bitangent) return fail(HRT_ERR_INVALID, "add_quad_ex: NULL argument");
+    s->scene.squares.emplace_back();
+    Square &q = s->scene.squares.back();
+    // the four vertices as they stand (after any rotate / scale / translate the caller applied), and the tangent frame as
+    // setQuad left it -- later transforms do NOT update m_right_vector / m_up_vector (Square.h:35-45, Scene.h:284)
+    q.vertices.resize(4);
+    const float *v[4] = {v0, v1, v2, v3};
+    for (int k = 0; k < 4; ++k) q.vertices[k].position = Vec3(v[k][0], v[k][1], v[k][2]);
+    q.triangles.resize(2);
+    q.triangles[0][0] = 0; q.triangles[0][1] = 1; q.triangles[0][2] = 2;
+    q.triangles[1][0] = 0; q.triangles[1][1] = 2; q.triangles[1][2] = 3;
+    q.m_bottom_left = q.vertices[0].position;
+    q.m_right_vector = Vec3(tangent[0], tangent[1], tangent[2]);
+    q.m_up_vector = Vec3(bitangent[0], bitangent[1], bitangent[2]);
+    q.build_arrays();
+    q.material = to_material(m);
+    return HRT_OK;
+}
+
 int hrt_host_scene_add_mesh(hrt_host_scene *s, const float *positions, uint32_t nv, const uint32_t *indices,
                             uint32_t nt, const float *face_colors, const hrt_material *m) {
+    return hrt_host_scene_add_mesh_ex(s, positions, nv, indices, nt, nullptr, face_colors, face_colors ? HRT_COLOR_FACE : HRT_COLOR_NONE, m);
+}
+
+int hrt_host_scene_add_mesh_ex(hrt_host_scene *s, const float *positions, uint32_t nv, const uint32_t *indices, uint32_t nt,
+                               const float *vert_colors, const float *face_colors, int32_t color_type, const hrt_material *m) {
     if (!s || (!positions && nv) || (!indices && nt)) return fail(HRT_ERR_INVALID, "add_mesh: NULL argument");
+    if (color_type < HRT_COLOR_VERTEX || color_type > HRT_COLOR_NONE) return fail(HRT_ERR_INVALID, "add_mesh: bad color_type");
     for (uint32_t i = 0; i < 3 * nt; ++i)
         if (indices[i] >= nv) return fail(HRT_ERR_INVALID, "add_mesh: vertex index out of range");
     s->scene.meshes.emplace_back();
@@ -140,10 +167,17 @@ int hrt_host_scene_add_mesh(hrt_host_scene *s, const float *positions, uint32_t 
         for (int k = 0; k < 3; ++k) mesh.triangles[t][k] = indices[3 * t + k];
         mesh.triangles[t][3] = t;
     }
-    if (face_colors) {
+    // Mesh::colorType decides what Scene::rayTraceRecursive reads (Scene.h:288-299); an array that is not given falls back
+    // to the material's albedo, as a mesh loaded from a plain OFF file does
+    mesh.colorType = ColorType_None;
+    if (color_type == HRT_COLOR_FACE && face_colors) {
         mesh.colorType = ColorType_Face;
         mesh.faceColors.resize(nt);
         for (uint32_t t = 0; t < nt; ++t) mesh.faceColors[t] = Vec3(face_colors[3 * t], face_colors[3 * t + 1], face_colors[3 * t + 2]);
+    } else if (color_type == HRT_COLOR_VERTEX && vert_colors) {
+        mesh.colorType = ColorType_Vertex;
+        mesh.vertColors.resize(nv);
+        for (uint32_t v = 0; v < nv; ++v) mesh.vertColors[v] = Vec3(vert_colors[3 * v], vert_colors[3 * v + 1], vert_colors[3 * v + 2]);
     }
     mesh.build_arrays();
     mesh.material = to_material(m);

@@ -235,6 +235,15 @@ int hrt_render_tiles(hrt_scene *scene, const hrt_camera *cam, uint32_t w,
 int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded,
                        uint32_t w, uint32_t h, uint32_t world,
                        float *d_frame /* device, h*w*3 */, void *stream);
+/* One hrt_scene carries one launch at a time (it owns the work-queue head, the path pool and the camera block of the
+ * launch).  Launches of the same scene on ONE stream are ordered by the stream; a launch on a different stream is made
+ * to wait for the previous one.  Two scenes never interfere.
+ *
+ * hrt_check_last_launch: waits for the last launch of this scene and returns HRT_ERR_DEVICE when the trace kernel gave
+ * up (its scheduler has a cycle bound so that a bug can never spin the GPU): the tiles of that launch are then
+ * incomplete and must not be used.  hrt_render and hrt_last_kernel_ms call it themselves; callers of the asynchronous
+ * entry points (hrt_render_tiles, hrt_render_accumulate) call it before they consume or ship the tiles. */
+int hrt_check_last_launch(hrt_scene *scene);
 /* Timing of the last hrt_render_tiles on this scene (after a sync). */
 int hrt_last_kernel_ms(hrt_scene *scene, double *ms);
 int hrt_kernel_info(hrt_stats *out);

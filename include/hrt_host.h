@@ -46,10 +46,21 @@ int hrt_host_scene_add_sphere(hrt_host_scene *s, const float center[3], float ra
 int hrt_host_scene_add_quad(hrt_host_scene *s, const float bottom_left[3], const float right[3],
                             const float up[3], float width, float height,
                             const hrt_material *material);
+/* A reference Square as it STANDS in a scene: vertices[0..3].position after whatever rotate / scale / translate the
+ * set-up code applied (Mesh.h:173-224), and the tangent frame m_right_vector / m_up_vector exactly as setQuad left it --
+ * un-normalised (length = width / height) and NOT touched by those later transforms (Square.h:35-45, Scene.h:284,
+ * SURVEY N5).  Square::intersect reads vertices 0, 1, 3 (Square.h:68-70); the normal map uses the stored frame. */
+int hrt_host_scene_add_quad_ex(hrt_host_scene *s, const float v0[3], const float v1[3], const float v2[3], const float v3[3],
+                               const float tangent[3], const float bitangent[3], const hrt_material *material);
 int hrt_host_scene_add_mesh(hrt_host_scene *s, const float *positions, uint32_t n_vertices,
                             const uint32_t *indices, uint32_t n_triangles,
                             const float *face_colors /* 3*n_triangles or NULL */,
                             const hrt_material *material);
+/* The same with the reference Mesh's colour members (Mesh.h:113-115): vertColors (3*n_vertices), faceColors
+ * (3*n_triangles), colorType (HRT_COLOR_*); Scene.h:288-299 decides by colorType. */
+int hrt_host_scene_add_mesh_ex(hrt_host_scene *s, const float *positions, uint32_t n_vertices,
+                               const uint32_t *indices, uint32_t n_triangles, const float *vert_colors,
+                               const float *face_colors, int32_t color_type, const hrt_material *material);
 int hrt_host_scene_add_mesh_off(hrt_host_scene *s, const char *off_path_relative_to_root,
                                 const hrt_material *material);
 int hrt_host_scene_add_light(hrt_host_scene *s, const float pos[3], float radius, const float color[3]);

@@ -1,6 +1,8 @@
 """Output stage on the device: progressive accumulation / resume and the PPM encoders.
 Everything here is bit-exact: the progressive path must leave the bits of the one-shot render, and the
 encoded file must be the bytes the reference's `ofstream <<` loop writes (main.cpp:258-262)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -137,3 +139,40 @@ def test_raytracer_driver_writes_the_file_the_library_renders(gpu, tmp_path):
     desc, dev, cam = build(gpu, "cornell_mesh", w / h)
     img, _ = dev.render(cam, w, h, spp, seed=seed, flags=gpu.FLAG_GAMMA)
     assert out.read_bytes() == gpu.ppm_text_reference(img)
+
+
+def test_a_launch_that_gives_up_is_reported_not_returned(gpu, tmp_path):
+    """The streaming kernel's scheduler has a cycle bound so that a bug can never spin the GPU.  libhrt_var_bound.so is the
+    same library built with the bound at 3 cycles (Makefile): every entry point that hands back pixels must then fail
+    with HRT_ERR_DEVICE -- hrt_render (with and without stats), hrt_check_last_launch after the asynchronous entry points,
+    hrt_last_kernel_ms -- and the process must stay usable (the lane-per-pixel kernel has no such bound and still renders)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import ctypes as C, importlib, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        hrt = importlib.import_module("hai719-raytracing_amd")
+        import torch
+        hrt.init(0)
+        w, h = 64, 48
+        host = hrt.HostScene().setup("cornell_mesh", w / h, 1); desc = host.flatten(); cam = hrt.default_camera(w / h)
+        dev = hrt.DeviceScene(desc)
+        lib = hrt.device_lib()
+        out = np.empty((h, w, 3), np.float32)
+        rc1 = lib.hrt_render(dev._h, C.byref(cam), w, h, 8, 1, hrt.FLAG_STREAM_KERNEL, out.ctypes.data, None)
+        st = hrt.Stats()
+        rc2 = lib.hrt_render(dev._h, C.byref(cam), w, h, 8, 1, hrt.FLAG_STREAM_KERNEL, out.ctypes.data, C.byref(st))
+        msg = lib.hrt_last_error().decode()
+        tiles = torch.zeros((hrt.tiles_total(w, h), 64, 3), dtype=torch.float32, device="cuda")
+        dev.render_tiles(cam, w, h, 8, 1, hrt.FLAG_STREAM_KERNEL, 0, 1, tiles.data_ptr(), 0)
+        rc3 = lib.hrt_check_last_launch(dev._h)
+        ms = C.c_double()
+        rc4 = lib.hrt_last_kernel_ms(dev._h, C.byref(ms))
+        img, _ = dev.render(cam, w, h, 2, 1, flags=hrt.FLAG_WAVE_KERNEL)   # still alive
+        print("RC", rc1, rc2, rc3, rc4, float(img.max()) > 0, "|", msg)
+    ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    env = dict(os.environ, HRT_LIBNAME="libhrt_var_bound.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("RC")][0]
+    assert line.startswith("RC -2 -2 -2 -2 True |") and "gave up" in line, line
