@@ -15,11 +15,20 @@ samples per pixel grow as 256*N so every GPU traces the same 530.8 M samples as 
 
 (HRT_BENCH_SHARE_GPU=1 rehearses the N > 1 path on a one-GPU box: all ranks share GPU 0, collectives over gloo.)
 
-Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel's algorithmic bytes (SURVEY.md
-8(d) record sizes x committed per-sample work counters) against the 8 TB/s HBM peak, with the
-kernel's launch duration measured by HIP events on the launch stream.  `cpu_baseline` is the CPU
-oracle (a port of the reference algorithm, reference-shaped KD-tree) timed on this host on a
-bounded sample of the same workload -- a reported baseline, not the target.
+Rank 0 prints ONE JSON line.  What its evidence keys mean:
+  roofline      memory side of the dominant kernel.  `traffic` = bytes per launch that crossed the L2 <-> fabric boundary,
+                (FETCH_SIZE x 2 + WRITE_SIZE) from the committed rocprofv3 PMC passes of THIS build (profiles/, separate
+                --pmc runs, gfx950 correction of MI355X_MICROARCH.md 'HBM'); Infinity-Cache hits are in that count, so it
+                is an UPPER bound on HBM bytes.  achieved = traffic / the kernel's launch duration measured live here with
+                HIP events on the launch stream; frac = achieved / 8 TB/s and cannot exceed 1 by construction of the
+                counters.  `algorithmic` keeps SURVEY 8(d)'s convention (fixed record sizes x per-sample work counters)
+                as information only: those records are served from SGPRs, LDS and L2, not from HBM.
+  valu          the bound that actually binds: SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES summed over SIMDs), i.e. the share
+                of SIMD cycles that issued vector work, with the lane utilisation of that work beside it (same PMC runs).
+  value_host_to_host   the same frame through hrt_render: gamma, tile assemble and the D2H copy of the frame included.
+  other_configs        kernel time of BASELINE's other configurations at their true sizes (one launch each).
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, reference-shaped KD-tree) timed on this host on a
+                bounded sample of the same workload, threaded three ways -- a reported baseline, not the target.
 """
 import argparse
 import importlib
@@ -48,38 +57,74 @@ def algorithmic_bytes_per_sample(w, h, spp):
     return b + 12.0 / spp, c
 
 
-def measured_traffic_bytes_per_launch():
-    """HBM bytes per trace-kernel launch from the rocprofv3 PMC passes, if a summary is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def committed_pmc():
+    """Counters of the trace kernel for this workload from the committed rocprofv3 PMC summary of this build
+    (profiles/r02_pmc.json, written by tools/profile.sh + tools/pmc_summary.py), or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         j = json.load(f)
-    key = f"{SCENE}_{W}x{H}@{SPP}"
-    return j.get(key, {}).get("hbm_bytes_per_launch")
+    return j if j.get("config", "").startswith(f"{SCENE} {W}x{H}@{SPP}") else None
 
 
 def cpu_baseline(hrt, desc, cam):
+    """The oracle on a bounded sample, ~8 s per leg: (1) a pool of hardware_concurrency threads over scanlines with
+    per-path random streams -- the `value`; (2) one std::thread per scanline, all spawned at once, as the reference does
+    (main.cpp:232-238); (3) the pool drawing every random number from ONE shared generator, the reference's
+    random_float() (Functions.cpp:4-8; mutex-protected here, a data race there)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    w, h = 480, 270  # bounded sample of the same scene / camera / seed, spp sized for ~15 s of CPU work
+    w, h = 480, 270  # bounded sample of the same scene / camera / seed
     threads = os.cpu_count() or 1
     scene = oracle_lib.OracleScene(desc, oracle_lib.MESH_REF_TREE)
-    t0 = time.perf_counter()
     scene.render(cam, w, h, 2, seed=SEED, threads=threads)  # page the scene in, start the thread pool once
     t0 = time.perf_counter()
-    scene.render(cam, w, h, 32, seed=SEED, threads=threads)  # calibration
-    rate = w * h * 32 / max(time.perf_counter() - t0, 1e-3)
-    spp = int(min(1024, max(8, 12.0 * rate / (w * h))))
+    scene.render(cam, w, h, 16, seed=SEED, threads=threads)  # calibration
+    rate = w * h * 16 / max(time.perf_counter() - t0, 1e-3)
+    spp = int(min(1024, max(4, 8.0 * rate / (w * h))))
+
+    def leg(nthreads, flags, spp_):
+        t0 = time.perf_counter()
+        scene.render(cam, w, h, spp_, seed=SEED, threads=nthreads, flags=flags)
+        dt = time.perf_counter() - t0
+        return round(w * h * spp_ / dt / 1e6, 4), round(dt, 1)
+
+    pool, dt_pool = leg(threads, 0, spp)
+    per_line, dt_line = leg(-1, 0, spp)
     t0 = time.perf_counter()
-    scene.render(cam, w, h, spp, seed=SEED, threads=threads)
-    dt = time.perf_counter() - t0
+    scene.render(cam, w, h, 1, seed=SEED, threads=threads, flags=1 << 16)
+    shared_rate = w * h / max(time.perf_counter() - t0, 1e-3)
+    shared_spp = int(min(spp, max(1, 6.0 * shared_rate / (w * h))))
+    shared, dt_shared = leg(threads, 1 << 16, shared_spp)
     return {
-        "value": round(w * h * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "value": pool, "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": f"{SCENE} {w}x{h}@{spp} spp, same camera and seed, oracle (reference-shaped KD-tree), "
-                  f"{threads} threads over scanlines, {dt:.1f} s",
+                  f"{threads} threads over scanlines, {dt_pool} s",
+        "thread_per_scanline": {"value": per_line, "threads": h, "seconds": dt_line,
+                                "note": "one std::thread per scanline, all started at once (main.cpp:232-238)"},
+        "shared_rng": {"value": shared, "threads": threads, "spp": shared_spp, "seconds": dt_shared,
+                       "note": "every draw from one process-wide mt19937 (random_float(), Functions.cpp:4-8; mutex here, a race there)"},
     }
+
+
+OTHER_CONFIGS = [("cfg1", "cornell_box", 256, 256, 4), ("cfg2", "cornell_mesh", 1920, 1080, 64), ("cfg3", "random_spheres", 1920, 1080, 256),
+                 ("cfg4", "mesh_in_box", 3840, 2160, 512), ("cfg5", "backrooms_pool", 3840, 2160, 1024)]
+
+
+def other_configs(hrt):
+    """Kernel time of BASELINE.json's other configurations at their true sizes on this GPU: one launch each (~12 s)."""
+    out = {}
+    for tag, name, w, h, spp in OTHER_CONFIGS:
+        dev = hrt.DeviceScene(hrt.HostScene().setup(name, w / h, 1).flatten())
+        cam = hrt.default_camera(w / h)
+        dev.render(cam, 64, 64, 1, SEED)  # first-launch costs out of the way
+        _, st = dev.render(cam, w, h, spp, SEED)
+        out[tag] = {"scene": name, "size": f"{w}x{h}@{spp}", "kernel_ms": round(st.kernel_ms, 2),
+                    "msamples_per_s": round(w * h * spp / st.kernel_ms / 1e3, 1)}
+        dev.close()
+    return out
 
 
 def main():
@@ -89,6 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU (default: the metric's 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host and other_configs (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -159,8 +205,26 @@ def main():
         bps, counts = algorithmic_bytes_per_sample(W, H, spp)
         launch_samples = W * H * spp / world  # what ONE launch (this rank's tiles) traces
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-        achieved = bps * launch_samples / avg_kernel_s / 1e9
-        traffic = measured_traffic_bytes_per_launch() if (world == 1 and args.spp == SPP) else None
+        pmc = committed_pmc() if (world == 1 and args.spp == SPP) else None
+        traffic = pmc["derived"]["fabric_bytes_per_launch"] if pmc else None
+        achieved = traffic / avg_kernel_s / 1e9 if traffic else None
+        roofline = {
+            "bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": None if not pmc else pmc["source"],
+            "algorithmic": {"bytes_per_sample": round(bps, 1), "bytes_per_launch": round(bps * launch_samples),
+                            "gbps": round(bps * launch_samples / avg_kernel_s / 1e9, 1),
+                            "note": "SURVEY 8(d) convention (record sizes x work counters): served from SGPRs / LDS / L2, not a bandwidth"},
+            "note": "achieved = L2<->fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included: an upper "
+                    "bound on HBM bytes) / the kernel's live HIP-event time; the kernel is VALU / latency bound, see valu",
+        }
+        valu = None
+        if pmc:
+            d = pmc["derived"]
+            valu = {"active_simd_cycles": d["valu_active_simd_cycles"], "peak_simd_cycles": d["simd_cycles"],
+                    "frac": d["valu_busy_frac"], "lane_utilisation": d["valu_lane_utilisation"],
+                    "valu_wave_insts_per_sample": d["valu_wave_insts_per_sample"],
+                    "note": "SQ_ACTIVE_INST_VALU over SQ_BUSY_CYCLES x SIMDs (quad-cycles both), same rocprofv3 PMC runs as traffic"}
         out = {
             "metric": "Msamples/s (pixels x spp / s), Cornell+mesh 1080p@256spp",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,14 +234,20 @@ def main():
                                    f"seed {SEED}, default camera", "spp_per_gpu_share": args.spp,
                        "partition": f"8x8 tiles round-robin over {world} rank(s), one gather to rank 0"},
             "kernel_ms_per_launch": round(avg_kernel_s * 1e3, 3),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_sample": round(bps, 1),
-                         "note": "achieved = SURVEY 8(d) algorithmic bytes / kernel time; those records are served from SGPRs, LDS "
-                                 "and L2, so frac can exceed 1; traffic = L2<->fabric bytes per launch from rocprofv3 PMC (path records)"},
+            "roofline": roofline, "valu": valu,
         }
         if frame is not None:
             out["frame_mean"] = round(float(frame.mean().item()), 6)
+        if world == 1 and not args.no_extras:
+            import numpy as np
+            host_img, st = scene.render(cam, W, H, spp, SEED, flags=hrt.FLAG_GAMMA)  # once to size the library's buffers
+            t1 = time.perf_counter()
+            host_img, st = scene.render(cam, W, H, spp, SEED, flags=hrt.FLAG_GAMMA)
+            dt = time.perf_counter() - t1
+            out["value_host_to_host"] = {"value": round(W * H * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms": round(dt * 1e3, 2),
+                                         "note": "hrt_render: kernel + gamma + tile assemble + D2H of the 24.9 MB frame, host call to host buffer"}
+            assert np.isfinite(host_img).all()
+            out["other_configs"] = other_configs(hrt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hrt, desc, cam)
         print(json.dumps(out), flush=True)

@@ -163,6 +163,13 @@ def device_lib() -> C.CDLL:
         lib.hrt_finalize_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.hrt_encode_ppm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t), C.c_void_p]
+        lib.hrt_multi_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        lib.hrt_multi_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                         C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        lib.hrt_multi_destroy.argtypes = [C.c_void_p]
+        lib.hrt_multi_destroy.restype = None
+        lib.hrt_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                         C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_void_p, C.POINTER(Stats)]
         lib.hrt_debug_kat.argtypes = [C.c_uint32, C.POINTER(Camera), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _dev = lib
     return _dev
@@ -364,6 +371,51 @@ def debug_kat(which: int, inp, prim=None, cam: Optional[Camera] = None) -> np.nd
     if rc < 0:
         raise HrtError(f"hrt_debug_kat failed ({rc}): {lib.hrt_last_error().decode()}")
     return out
+
+
+class MultiScene:
+    """``hrt_multi``: one replica of the scene per slot of ``devices`` (ordinals; may repeat), image tiles across them."""
+
+    def __init__(self, desc: C.c_void_p, devices):
+        global _inited
+        self._lib = device_lib()
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self._lib.hrt_multi_create(desc, len(devices), arr, C.byref(self._h))
+        if rc < 0:
+            raise HrtError(f"hrt error {rc}: {self._lib.hrt_last_error().decode()}")
+        _inited = True
+
+    def close(self):
+        if self._h:
+            self._lib.hrt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam: Camera, w: int, h: int, spp: int, seed: int = 1, flags: int = 0):
+        out = np.empty((h, w, 3), dtype=np.float32)
+        st = Stats()
+        rc = self._lib.hrt_multi_render(self._h, C.byref(cam), w, h, spp, seed, flags, out.ctypes.data, C.byref(st))
+        if rc < 0:
+            raise HrtError(f"hrt error {rc}: {self._lib.hrt_last_error().decode()}")
+        return out, st
+
+
+def render_multi(desc, cam: Camera, w: int, h: int, spp: int, seed: int, flags: int, devices):
+    """hrt_render_multi: create + render + destroy in one call."""
+    lib = device_lib()
+    out = np.empty((h, w, 3), dtype=np.float32)
+    st = Stats()
+    arr = (C.c_int * len(devices))(*devices)
+    rc = lib.hrt_render_multi(desc, C.byref(cam), w, h, spp, seed, flags, len(devices), arr, out.ctypes.data, C.byref(st))
+    if rc < 0:
+        raise HrtError(f"hrt error {rc}: {lib.hrt_last_error().decode()}")
+    return out, st
 
 
 def tiles_total(w: int, h: int) -> int:

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -39,7 +40,18 @@ struct Runtime {
     bool use_dual = true;     // two pixel streams per lane (hrt_dual.hip) for scenes with meshes; HRT_KERNEL=single turns it off
     int use_stream = -1;      // workgroup-streaming kernel (hrt_stream.hip): -1 where it pays (default), 1 always (HRT_KERNEL=stream), 0 never
     hipFuncAttributes attr{};
+    std::vector<int> dev_cus;  // per ordinal: CUs of the devices hrt_init has prepared (0 = not prepared); one process may drive several
 } g_rt;
+
+// Makes `ordinal` (a device hrt_init has prepared) the current one for this thread and for the launch geometry.
+int use_device(int ordinal) {
+    if (ordinal < 0 || ordinal >= (int)g_rt.dev_cus.size() || g_rt.dev_cus[ordinal] == 0)
+        return fail(HRT_ERR_STATE, "device " + std::to_string(ordinal) + " has not been initialised (hrt_init)");
+    HIP_TRY(hipSetDevice(ordinal));
+    g_rt.device = ordinal;
+    g_rt.cus = g_rt.dev_cus[ordinal];
+    return HRT_OK;
+}
 
 float as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
@@ -186,6 +198,7 @@ struct hrt_scene {
     size_t tiles_cap = 0, frame_cap = 0;
     uint32_t last_grid = 0, last_waves = 0, last_lds = 0;
     hipStream_t last_stream = nullptr;  // stream of the previous launch on this scene
+    int device = 0;                     // the device that holds this scene (current when it was created)
 };
 
 extern "C" {
@@ -208,6 +221,8 @@ int hrt_init(int device_ordinal) {
     HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     g_rt.device = device_ordinal;
     g_rt.cus = prop.multiProcessorCount;
+    if ((int)g_rt.dev_cus.size() < n) g_rt.dev_cus.resize((size_t)n, 0);
+    if (g_rt.dev_cus[device_ordinal] != 0) { g_rt.ready = true; return HRT_OK; }  // this device is prepared already: it is current again
     HIP_TRY(hipFuncGetAttributes(&g_rt.attr, (const void *)hrt_trace_kernel));
     // LDS for nodelets per 256-thread workgroup.  Default 32 KiB (4 workgroups/CU keep 128 of the
     // CU's 160 KiB); HRT_LDS_KB overrides for tuning.
@@ -244,14 +259,16 @@ int hrt_init(int device_ordinal) {
         g_rt.use_dual = ks != "single";
         g_rt.use_stream = ks == "stream" ? 1 : ((ks == "single" || ks == "dual") ? 0 : -1);
     }
+    g_rt.dev_cus[device_ordinal] = prop.multiProcessorCount;
     g_rt.ready = true;
     return HRT_OK;
 }
 
-void hrt_shutdown(void) { g_rt.ready = false; }
+void hrt_shutdown(void) { g_rt.ready = false; g_rt.dev_cus.clear(); }
 
 void hrt_scene_destroy(hrt_scene *s) {
     if (!s) return;
+    if (g_rt.ready && s->device != g_rt.device) (void)use_device(s->device);
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->tile_counter) (void)hipFree(s->tile_counter);
     if (s->stamps) (void)hipFree(s->stamps);
@@ -536,6 +553,7 @@ int hrt_scene_create(const hrt_scene_desc *desc, hrt_scene **out) {
     hrt_scene *s = nullptr;
     try {
         s = new hrt_scene();
+        s->device = g_rt.device;
         int rc = scene_create_impl(desc, s);
         if (rc != HRT_OK) {
             std::string keep = g_error;
@@ -617,6 +635,7 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
                        uint32_t flags, uint32_t rank, uint32_t world, DRender &R, hipStream_t stream) {
     if (!s || !cam) return fail(HRT_ERR_INVALID, "render: NULL argument");
     if (!g_rt.ready) return fail(HRT_ERR_STATE, "render: call hrt_init first");
+    if (s->device != g_rt.device) { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }  // a scene lives on its device
     if (!w || !h || !spp) return fail(HRT_ERR_INVALID, "render: w, h and spp must be positive");
     if ((uint64_t)w * h > 0x7fffffffull) return fail(HRT_ERR_INVALID, "render: image too large");
     if (w > 65535u || h > 65535u) return fail(HRT_ERR_INVALID, "render: w and h must be below 65536 (tile origins are packed in 16 + 16 bits)");
@@ -850,6 +869,7 @@ int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, uns
 int hrt_check_last_launch(hrt_scene *s) {
     if (!s) return fail(HRT_ERR_INVALID, "hrt_check_last_launch: NULL scene");
     if (!s->timed) return HRT_OK;
+    if (s->device != g_rt.device) { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }
     HIP_TRY(hipEventSynchronize(s->ev1));
     unsigned long long gave_up = 0;
     HIP_TRY(hipMemcpy(&gave_up, s->stamps + 15, sizeof(gave_up), hipMemcpyDeviceToHost));
@@ -1052,5 +1072,7 @@ int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h) {
     std::fclose(f);
     return HRT_OK;
 }
+
+#include "hrt_multi.hip"
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 //
 //   raytracer [--scene cornell_box|cornell_mesh|random_spheres|mesh_in_box|backrooms_pool]
 //             [--w 850] [--h 480] [--spp 20] [--seed 1] [--out ./rendu.ppm] [--assets DIR] [--gpu 0]
+//             [--gpus N | --devices 0,1,2,...]   image tiles across several GPUs of this node (hrt_multi_*; an ordinal may repeat)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,8 @@ static std::string out_path = "./rendu.ppm";
 
 // Drop-in for ray_trace_from_camera(): same inputs (current scene, nsamples, window size, camera),
 // same output file and quantisation; returns non-zero instead of printing-and-returning on failure.
+static hrt_multi *multi = nullptr;  // --gpus / --devices: the same frame, tiles across several GPUs
+
 static int ray_trace_from_camera() {
     const unsigned w = SCREENWIDTH, h = SCREENHEIGHT;
     std::vector<float> image((size_t)w * h * 3, 0.f);
@@ -34,7 +37,8 @@ static int ray_trace_from_camera() {
     std::cout << "Ray tracing a " << w << " x " << h << " image on the GPU using " << nsamples
               << " samples per pixel" << std::endl;
     hrt_stats st;
-    int rc = hrt_render(device_scene, &cam, w, h, nsamples, seed, HRT_FLAG_GAMMA, image.data(), &st);
+    int rc = multi ? hrt_multi_render(multi, &cam, w, h, nsamples, seed, HRT_FLAG_GAMMA, image.data(), &st)
+                   : hrt_render(device_scene, &cam, w, h, nsamples, seed, HRT_FLAG_GAMMA, image.data(), &st);
     if (rc != HRT_OK) {
         std::cout << "hrt_render failed: " << hrt_last_error() << std::endl;
         return rc;
@@ -49,6 +53,7 @@ static int ray_trace_from_camera() {
 int main(int argc, char **argv) {
     std::string name = "cornell_box", assets = "assets";
     int gpu = 0;
+    std::vector<int> devices;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--scene") name = v;
@@ -59,6 +64,11 @@ int main(int argc, char **argv) {
         else if (k == "--out") out_path = v;
         else if (k == "--assets") assets = v;
         else if (k == "--gpu") gpu = atoi(v.c_str());
+        else if (k == "--gpus") { devices.clear(); for (int d = 0; d < atoi(v.c_str()); ++d) devices.push_back(d); }
+        else if (k == "--devices") {
+            devices.clear();
+            for (size_t a = 0; a < v.size();) { size_t b = v.find(',', a); if (b == std::string::npos) b = v.size(); devices.push_back(atoi(v.substr(a, b - a).c_str())); a = b + 1; }
+        }
         else { std::cerr << "unknown option " << k << std::endl; return 2; }
     }
     scene.asset_root = assets;
@@ -67,12 +77,15 @@ int main(int argc, char **argv) {
         return EXIT_FAILURE;  // the reference exit()s on a missing mesh (Mesh.cpp:12-13)
     }
     std::unique_ptr<FlatScene> flat = scene.flatten();
-    if (hrt_init(gpu) != HRT_OK || hrt_scene_create(&flat->desc, &device_scene) != HRT_OK) {
+    const int up = devices.empty() ? (hrt_init(gpu) != HRT_OK ? HRT_ERR_DEVICE : hrt_scene_create(&flat->desc, &device_scene))
+                                   : hrt_multi_create(&flat->desc, (uint32_t)devices.size(), devices.data(), &multi);
+    if (up != HRT_OK) {
         std::cerr << hrt_last_error() << std::endl;
         return EXIT_FAILURE;
     }
     int rc = ray_trace_from_camera();  // the 'r' key
     hrt_scene_destroy(device_scene);
+    hrt_multi_destroy(multi);
     hrt_shutdown();
     return rc == HRT_OK ? 0 : EXIT_FAILURE;
 }

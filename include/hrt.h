@@ -204,6 +204,8 @@ typedef struct hrt_stats {
 
 typedef struct hrt_scene hrt_scene;   /* opaque: device-resident SoA scene */
 
+/* Prepares `device_ordinal` (once) and makes it the current device of the library: scenes are created on the current
+ * device and stay there.  May be called for several devices; entry points that take a scene switch to its device. */
 int hrt_init(int device_ordinal);
 void hrt_shutdown(void);
 const char *hrt_last_error(void);
@@ -220,6 +222,24 @@ void hrt_scene_destroy(hrt_scene *scene);
 int hrt_render(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
                uint32_t spp, uint64_t seed, uint32_t flags, float *out_rgb,
                hrt_stats *stats /* may be NULL */);
+
+/* Several GPUs from ONE process -- the multi-GPU form of the reference's single caller ray_trace_from_camera()
+ * (main.cpp:200-263).  Slot i of `device_ordinals` holds a replica of the scene on that device, renders the image tiles
+ * i, i + n, i + 2n, ... on a stream of its own (all slots run at once), and its dense tile buffer is copied device to
+ * device (xGMI between GPUs) into its block of a gather buffer on slot 0's device: ONE gather step, no reduction (slots
+ * own disjoint pixels).  Slot 0 then de-interleaves the tiles and copies the frame to out_rgb (host, h*w*3).  The pixels
+ * are bit-identical to hrt_render's for any number of slots.  An ordinal may be repeated (several slots share a GPU),
+ * which makes the path testable on a one-GPU machine.  hrt_multi_create prepares every listed device (hrt_init is not
+ * needed first) and leaves slot 0's device current; stats: kernel_ms = the slowest slot's kernel.
+ * hrt_render_multi = create + render + destroy in one call. */
+typedef struct hrt_multi hrt_multi;
+int hrt_multi_create(const hrt_scene_desc *desc, uint32_t n_devices, const int *device_ordinals, hrt_multi **out);
+int hrt_multi_render(hrt_multi *m, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
+                     uint32_t flags, float *out_rgb, hrt_stats *stats /* may be NULL */);
+void hrt_multi_destroy(hrt_multi *m);
+int hrt_render_multi(const hrt_scene_desc *desc, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp,
+                     uint64_t seed, uint32_t flags, uint32_t n_devices, const int *device_ordinals, float *out_rgb,
+                     hrt_stats *stats /* may be NULL */);
 
 /* Multi-GPU building blocks (device pointers; `stream` is a hipStream_t cast
  * to void*, NULL = the default stream).  Asynchronous w.r.t. the host. */

@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <thread>
 #include <vector>
@@ -97,6 +98,18 @@ struct Counters {  // per-sample work counters
     }
 };
 
+// Timing-only mode of oracle_render (flag ORACLE_FLAG_SHARED_RNG): every draw comes from ONE process-wide mt19937, as the
+// reference's random_float() does (a static generator shared by all row threads, Functions.cpp:4-8).  The reference
+// does not synchronise it (a data race); here a mutex keeps it defined.  Pixels are then not reproducible: this exists to
+// time the reference's contention pattern beside the thread-local form, never for parity.
+static bool g_shared_rng = false;
+static std::mutex g_shared_rng_mutex;
+static std::mt19937 g_shared_rng_gen(12345u);
+static float shared_random_float() {
+    std::lock_guard<std::mutex> lock(g_shared_rng_mutex);
+    return std::uniform_real_distribution<float>(0.f, 1.f)(g_shared_rng_gen);
+}
+
 // Counter-based per-path stream: draw i of path (seed, pixel, sample).
 struct PathRng {
     uint32_t k0, k1, i;
@@ -106,6 +119,7 @@ struct PathRng {
         k1 = mix32((uint32_t)(seed >> 32) + sample * 0x85EBCA77u + 0xC2B2AE3Du);
     }
     float next() {  // stands in for random_float(), Functions.cpp:4-8
+        if (g_shared_rng) return shared_random_float();
         uint32_t x = k0 + (i++) * 0x9E3779B9u;
         x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x ^= k1; x *= 0x846ca68bu; x ^= x >> 16;
         if (cnt) cnt->rng_draws++;
@@ -874,6 +888,8 @@ int oracle_render(const oracle_scene *o, const hrt_camera *cam, uint32_t w, uint
     const OScene &S = o->S;
     const CameraMats cm = camera_matrices(*cam);
     const bool gamma = (flags & HRT_FLAG_GAMMA) != 0;
+    g_shared_rng = (flags & (1u << 16)) != 0;  // ORACLE_FLAG_SHARED_RNG (timing only; see shared_random_float)
+    struct Restore { ~Restore() { g_shared_rng = false; } } restore_shared_rng;
     Counters total;
     auto do_row = [&](uint32_t y, Counters *cnt) {
         for (uint32_t x = 0; x < w; ++x) {

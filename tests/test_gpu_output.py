@@ -176,3 +176,43 @@ def test_a_launch_that_gives_up_is_reported_not_returned(gpu, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("RC")][0]
     assert line.startswith("RC -2 -2 -2 -2 True |") and "gave up" in line, line
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_mesh", 200, 120, 3), ("random_spheres", 61, 35, 2), ("backrooms_pool", 128, 72, 2)])
+def test_render_multi_gives_the_bits_of_render(gpu, name, w, h, spp):
+    """hrt_multi_* / hrt_render_multi: one process, one replica + stream per slot, tiles r, r + N, ..., ONE gather of the
+    tile buffers to slot 0, assemble.  With every slot on GPU 0 (an ordinal may repeat) the path runs on a one-GPU box:
+    1, 2, 3 and 5 slots must each give exactly the frame hrt_render gives, with and without gamma."""
+    desc, dev, cam = build(gpu, name, w / h)
+    want, _ = dev.render(cam, w, h, spp, seed=9)
+    want_g, _ = dev.render(cam, w, h, spp, seed=9, flags=gpu.FLAG_GAMMA)
+    for slots in ([0], [0, 0], [0, 0, 0], [0] * 5):
+        ms = gpu.MultiScene(desc, slots)
+        got, st = ms.render(cam, w, h, spp, seed=9)
+        assert np.array_equal(got, want), f"{len(slots)} slots"
+        assert st.samples == w * h * spp and st.kernel_ms > 0
+        again, _ = ms.render(cam, w, h, spp, seed=9, flags=gpu.FLAG_GAMMA)   # buffers reused
+        assert np.array_equal(again, want_g)
+        ms.close()
+    one_shot, _ = gpu.render_multi(desc, cam, w, h, spp, 9, 0, [0, 0, 0])
+    assert np.array_equal(one_shot, want)
+    bigger, _ = gpu.render_multi(desc, cam, 3 * w, 2 * h, 1, 9, 0, [0, 0])
+    assert np.array_equal(bigger, dev.render(cam, 3 * w, 2 * h, 1, seed=9)[0])
+    with pytest.raises(gpu.HrtError):
+        gpu.MultiScene(desc, [0, 99])          # no such device
+    img, _ = dev.render(cam, w, h, spp, seed=9)  # the single-GPU scene still works afterwards
+    assert np.array_equal(img, want)
+
+
+def test_raytracer_driver_renders_across_slots(gpu, tmp_path):
+    """The headless driver (main.cpp without GLUT): --devices 0,0 writes the same PPM as the single-GPU run."""
+    import subprocess
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hai719-raytracing_amd")
+    outs = []
+    for extra in ([], ["--devices", "0,0"]):
+        out = os.path.join(str(tmp_path), f"r{len(outs)}.ppm")
+        r = subprocess.run([os.path.join(pkg, "raytracer"), "--scene", "cornell_mesh", "--w", "96", "--h", "54", "--spp", "3", "--seed", "4",
+                            "--assets", os.path.join(os.path.dirname(pkg), "assets"), "--out", out] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].startswith(b"P3\n96 54\n255\n")
