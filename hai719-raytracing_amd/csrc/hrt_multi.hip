@@ -26,6 +26,7 @@ struct hrt_multi {
 };
 
 static void multi_free_buffers(hrt_multi *m) {
+    if (!m->n || !m->replica[0]) return;  // creation failed before any buffer existed
     for (uint32_t i = 0; i < m->n; ++i)
         if (i < m->d_tiles.size() && m->d_tiles[i]) { (void)hipSetDevice(m->ordinal[i]); (void)hipFree(m->d_tiles[i]); m->d_tiles[i] = nullptr; }
     if (m->n) (void)hipSetDevice(m->ordinal[0]);
@@ -38,12 +39,14 @@ void hrt_multi_destroy(hrt_multi *m) {
     if (!m) return;
     multi_free_buffers(m);
     for (uint32_t i = 0; i < m->n; ++i) {
+        if (!m->replica[i]) continue;  // a slot hrt_multi_create never reached (e.g. a bad ordinal): nothing on it
         (void)hipSetDevice(m->ordinal[i]);
         if (i < m->stream.size() && m->stream[i]) (void)hipStreamDestroy(m->stream[i]);
         if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
         if (i < m->replica.size() && m->replica[i]) hrt_scene_destroy(m->replica[i]);
     }
-    if (m->n && g_rt.ready) (void)use_device(m->ordinal[0]);
+    if (m->n && g_rt.ready && m->replica[0]) (void)use_device(m->ordinal[0]);
+    (void)hipGetLastError();  // nothing above may leave a sticky error for the next launch check
     delete m;
 }
 
