@@ -142,11 +142,51 @@ void fold_quad(const hrt_quad &q, const hrt_material &m, std::vector<float4> &qu
     quads.push_back(make_float4(m.motion[0], m.motion[1], m.motion[2], as_float((uint32_t)q.material)));
     quads.push_back(make_float4(q.tangent[0], q.tangent[1], q.tangent[2], 0.f));
     quads.push_back(make_float4(q.bitangent[0], q.bitangent[1], q.bitangent[2], 0.f));
-    // the filter's copy (hrt_device.h): values identical to the rows above, only their order differs
-    quads.push_back(make_float4(v0.x, v0.y, v0.z, h_dot(v0, n)));
-    quads.push_back(make_float4(n.y, n.z, n.x, as_float(flags)));
-    quads.push_back(make_float4(R.x, U.x, R.y, U.y));
-    quads.push_back(make_float4(R.z, U.z, h_len(R), h_len(U)));
+}
+
+// The rows of the squares' no-division filter (hrt_device.h DScene::qfilter; hrt_kernels.hip quad_filter), from the folded
+// rows: sections for axis-aligned static squares by normal axis, then all others.  A square is "axis-aligned" only when
+// that is EXACTLY so in the folded fp32 values -- normal (+-1 on one axis K, zero elsewhere), R along one of the other two
+// axes and U along the remaining one: then every product with a zero component is an exact zero in the reference's
+// arithmetic and its plane distance reduces exactly to (p0_K - o_K) / d_K.
+void build_quad_filter(const std::vector<float4> &quads, uint32_t nq, std::vector<float4> &qf, uint32_t count[4]) {
+    std::vector<float4> sec[4];
+    for (int k = 0; k < 4; ++k) count[k] = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        const float4 *q = &quads[(size_t)HRT_QUAD_ROWS * i];
+        const float p0[3] = {q[0].x, q[0].y, q[0].z}, n[3] = {q[1].x, q[1].y, q[1].z}, R[3] = {q[2].x, q[2].y, q[2].z}, U[3] = {q[3].x, q[3].y, q[3].z};
+        uint32_t flags;
+        std::memcpy(&flags, &q[1].w, 4);
+        int K = -1;
+        if (!(flags & HRT_QUAD_FLAG_MOVING))
+            for (int k = 0; k < 3; ++k) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                const bool normal_ok = std::fabs(n[k]) == 1.f && n[a] == 0.f && n[b] == 0.f;
+                const bool ru = R[k] == 0.f && U[k] == 0.f && R[b] == 0.f && U[a] == 0.f && R[a] != 0.f && U[b] != 0.f;   // R along a, U along b
+                const bool ur = R[k] == 0.f && U[k] == 0.f && R[a] == 0.f && U[b] == 0.f && R[b] != 0.f && U[a] != 0.f;   // or the other way round
+                if (normal_ok && (ru || ur)) K = k;
+            }
+        if (K >= 0) {
+            const int a = (K + 1) % 3, b = (K + 2) % 3;
+            const double ea = (double)R[a] + (double)U[a], eb = (double)R[b] + (double)U[b];  // one of each pair is zero
+            // centres and half extents rounded outwards by an ulp: the filter must never be tighter than the exact test
+            const float ca = (float)((double)p0[a] + 0.5 * ea), cb = (float)((double)p0[b] + 0.5 * eb);
+            const float ha = std::nextafter((float)(0.5 * std::fabs(ea)) + std::fabs(ca) * 1.2e-7f, INFINITY);
+            const float hb = std::nextafter((float)(0.5 * std::fabs(eb)) + std::fabs(cb) * 1.2e-7f, INFINITY);
+            const uint32_t bits = ((flags & HRT_QUAD_FLAG_GLASS) ? 1u : 0u) | (n[K] < 0.f ? 2u : 0u) | (i << 8);
+            sec[K].push_back(make_float4(p0[K], ca, cb, ha));
+            sec[K].push_back(make_float4(hb, as_float(bits), 0.f, 0.f));
+            ++count[K];
+        } else {
+            sec[3].push_back(make_float4(p0[0], p0[1], p0[2], q[0].w));
+            sec[3].push_back(make_float4(n[1], n[2], n[0], as_float(flags | (i << 8))));
+            sec[3].push_back(make_float4(R[0], U[0], R[1], U[1]));
+            sec[3].push_back(make_float4(R[2], U[2], q[2].w, q[3].w));
+            ++count[3];
+        }
+    }
+    qf.clear();
+    for (int k = 0; k < 4; ++k) qf.insert(qf.end(), sec[k].begin(), sec[k].end());
 }
 
 // Triangle(c0,c1,c2) + computeBarycentricCoordinates constants (Triangle.h:26-37, 62-70) -> the 5 rows of hrt_device.h.
@@ -344,6 +384,8 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         const hrt_material &m = D.materials[q.material];
         fold_quad(q, m, quads);
     }
+    std::vector<float4> qfilter;
+    build_quad_filter(quads, D.n_quads, qfilter, s->d.qf_n);
     for (uint32_t i = 0; i < D.n_lights; ++i) {
         const hrt_light &l = D.lights[i];
         lights.push_back(make_float4(l.pos[0], l.pos[1], l.pos[2], l.radius));
@@ -358,6 +400,8 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         mats.push_back(make_float4(m.checker2[0], m.checker2[1], m.checker2[2], m.tex_scale_y));
         mats.push_back(make_float4(m.light_color[0], m.light_color[1], m.light_color[2], m.light_intensity));
         mats.push_back(make_float4(as_float((uint32_t)m.image), as_float((uint32_t)m.normal_map), 0.f, 0.f));
+        mats.push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // rows 6, 7: geometry of the texture / the normal map, filled in below
+        mats.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     }
 
     // ---- images -> RGBA8 words
@@ -375,6 +419,12 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 texels.push_back((uint32_t)im.rgb[3 * p] | ((uint32_t)im.rgb[3 * p + 1] << 8) | ((uint32_t)im.rgb[3 * p + 2] << 16));
         }
         images.push_back(di);
+    }
+
+    for (uint32_t i = 0; i < D.n_materials; ++i) {  // {texel offset, w, h} of each material's images, so that a lane need not chase the image table
+        const hrt_material &m = D.materials[i];
+        if (m.image >= 0) mats[(size_t)HRT_MAT_ROWS * i + 6] = make_float4(as_float(images[m.image].offset), as_float((uint32_t)images[m.image].w), as_float((uint32_t)images[m.image].h), 0.f);
+        if (m.normal_map >= 0) mats[(size_t)HRT_MAT_ROWS * i + 7] = make_float4(as_float(images[m.normal_map].offset), as_float((uint32_t)images[m.normal_map].w), as_float((uint32_t)images[m.normal_map].h), 0.f);
     }
 
     // ---- meshes: nodelets (refs rebased), leaf-ordered triangle soup, colours
@@ -517,10 +567,26 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         d.field = ptr;                                           \
     }
     (void)p4;
-    UP(spheres, spheres, float4)
-    UP(quads, quads, float4)
-    UP(mats, materials, float4)
-    UP(meshes, meshes, DMesh)
+    {   // squares | materials | spheres | mesh records in one array: `quads`, `materials`, `spheres`, `meshes` point into it
+        static_assert(sizeof(DMesh) % sizeof(float4) == 0, "mesh records are whole rows");
+        std::vector<float4> tabs;
+        d.tab_quads = 0;
+        tabs.insert(tabs.end(), quads.begin(), quads.end());
+        d.tab_mats = (uint32_t)tabs.size();
+        tabs.insert(tabs.end(), mats.begin(), mats.end());
+        d.tab_spheres = (uint32_t)tabs.size();
+        tabs.insert(tabs.end(), spheres.begin(), spheres.end());
+        d.tab_meshes = (uint32_t)tabs.size();
+        tabs.resize(tabs.size() + meshes.size() * (sizeof(DMesh) / sizeof(float4)));
+        if (!meshes.empty()) std::memcpy(&tabs[d.tab_meshes], meshes.data(), meshes.size() * sizeof(DMesh));
+        d.tab_rows = (uint32_t)tabs.size();
+        UP(tabs, tabs, float4)
+        d.quads = d.tabs + d.tab_quads;
+        d.materials = d.tabs + d.tab_mats;
+        d.spheres = d.tabs + d.tab_spheres;
+        d.meshes = reinterpret_cast<const DMesh *>(d.tabs + d.tab_meshes);
+    }
+    UP(qfilter, qfilter, float4)
     UP(units, kd_units, uint4)
     UP(tris, tris, float4)
     UP(colors, colors, float4)
@@ -687,7 +753,11 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     // workgroup-streaming kernel wins where bounces diverge -- meshes (+3..10 %) and lit open scenes (random_spheres
     // +30 %) -- and loses on a closed box of squares (-45 %), where the lane-per-pixel kernel keeps its lanes busy anyway.
     const bool stream_pays = s->d.n_meshes > 0u || s->d.n_lights > 0u;
-    const bool stream_kernel = !(flags & (HRT_FLAG_WAVE_KERNEL | HRT_FLAG_DUAL_KERNEL)) &&
+    // the streaming kernel stages the per-object tables (squares, materials, spheres, mesh records) in LDS beside its queues
+    const bool stream_fits = (size_t)s->d.tab_rows * 16u <= 48u * 1024u;
+    if ((flags & HRT_FLAG_STREAM_KERNEL) && !stream_fits)
+        return fail(HRT_ERR_INVALID, "render: the scene's object tables exceed the 48 KiB the streaming kernel keeps in LDS; use another kernel form");
+    const bool stream_kernel = stream_fits && !(flags & (HRT_FLAG_WAVE_KERNEL | HRT_FLAG_DUAL_KERNEL)) &&
                                (g_rt.use_stream == 1 || (flags & HRT_FLAG_STREAM_KERNEL) || (g_rt.use_stream < 0 && stream_pays));
     const bool exact = (flags & HRT_FLAG_EXACT_ONLY) != 0u;  // proof builds exist for the lane-per-pixel and streaming forms
     if ((flags & HRT_FLAG_MESH_BRUTE) && !exact) return fail(HRT_ERR_INVALID, "render: HRT_FLAG_MESH_BRUTE needs HRT_FLAG_EXACT_ONLY");
@@ -696,7 +766,8 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
                              !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
-        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4);
+        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4) +
+                               s->d.tab_rows * 16u;  // + the scene's per-object tables (stream_tables_fit)
         uint32_t per_cu = (64u * 4u * HRT_SP_MINW) / HRT_SP_WG;  // workgroups resident per CU (HRT_SP_MINW waves per SIMD in all) ...
         while (per_cu > 1u && 160u * 1024u / per_cu < fixed + 16u * 1024u) --per_cu;  // ... as far as the LDS pools allow
         const uint32_t room = (160u * 1024u / per_cu - fixed) / 16u;
@@ -996,10 +1067,13 @@ int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, cons
     if (which > HRT_KAT_NORMALIZE) return fail(HRT_ERR_INVALID, "hrt_debug_kat: unknown instrument");
     if ((which == HRT_KAT_CAMERA) != (cam != nullptr) || ((which >= HRT_KAT_TRIANGLE && which <= HRT_KAT_QUAD) != (prim != nullptr)))
         return fail(HRT_ERR_INVALID, "hrt_debug_kat: cam is for HRT_KAT_CAMERA, prim for the primitive instruments");
-    std::vector<float4> rows;
+    std::vector<float4> rows, kat_qf;
     std::vector<float> box;
     float err_abs = 0.f;
     DCamera C;
+    DScene kat_scene{};   // HRT_KAT_QUAD: carries nothing but the square's filter rows
+    float4 *d_qf = nullptr;
+    DScene *d_scene = nullptr;
     if (which == HRT_KAT_CAMERA) {
         const int rc = make_camera(cam, C);
         if (rc != HRT_OK) return rc;
@@ -1019,6 +1093,7 @@ int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, cons
         for (int k = 0; k < 3; ++k) { q.v0[k] = prim[k]; q.v1[k] = prim[3 + k]; q.v3[k] = prim[6 + k]; m.motion[k] = prim[9 + k]; }
         m.type = prim[12] != 0.f ? HRT_MAT_GLASS : HRT_MAT_DIFFUSE;
         fold_quad(q, m, rows);
+        build_quad_filter(rows, 1u, kat_qf, kat_scene.qf_n);
         double b = 0.0;
         for (int k = 0; k < 13; ++k) b = std::max(b, (double)std::fabs(prim[k]));
         for (size_t k = 0; k < (size_t)n * 7; ++k) if (k % 7 < 3) b = std::max(b, (double)std::fabs(in[k]));
@@ -1042,13 +1117,22 @@ int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, cons
             case HRT_KAT_TRIANGLE: hipLaunchKernelGGL(hrt_kat_triangle_kernel, grid, block, 0, 0, (const float4 *)d_prim, d_in, n, d_out); break;
             case HRT_KAT_AABB: hipLaunchKernelGGL(hrt_kat_aabb_kernel, grid, block, 0, 0, (const float *)d_prim, d_in, n, d_out); break;
             case HRT_KAT_SPHERE: hipLaunchKernelGGL(hrt_kat_sphere_kernel, grid, block, 0, 0, (const float4 *)d_prim, d_in, n, d_out); break;
-            case HRT_KAT_QUAD: hipLaunchKernelGGL(hrt_kat_quad_kernel, grid, block, 0, 0, (const float4 *)d_prim, d_in, n, err_abs, d_out); break;
+            case HRT_KAT_QUAD:
+                e = hipMalloc((void **)&d_qf, kat_qf.size() * sizeof(float4));
+                if (e == hipSuccess) e = hipMemcpy(d_qf, kat_qf.data(), kat_qf.size() * sizeof(float4), hipMemcpyHostToDevice);
+                kat_scene.qfilter = d_qf;
+                if (e == hipSuccess) e = hipMalloc((void **)&d_scene, sizeof(DScene));
+                if (e == hipSuccess) e = hipMemcpy(d_scene, &kat_scene, sizeof(DScene), hipMemcpyHostToDevice);
+                if (e == hipSuccess) hipLaunchKernelGGL(hrt_kat_quad_kernel, grid, block, 0, 0, (const float4 *)d_prim, (const DScene *)d_scene, d_in, n, err_abs, d_out);
+                break;
             case HRT_KAT_OPTICS: hipLaunchKernelGGL(hrt_kat_optics_kernel, grid, block, 0, 0, d_in, n, d_out); break;
             default: hipLaunchKernelGGL(hrt_kat_normalize_kernel, grid, block, 0, 0, d_in, n, d_out); break;
         }
-        e = hipGetLastError();
+        if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    if (d_qf) (void)hipFree(d_qf);
+    if (d_scene) (void)hipFree(d_scene);
     if (d_prim) (void)hipFree(d_prim);
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);

@@ -9,9 +9,11 @@
 //     sphere  2 rows: {c.xyz, r} {motion.xyz, material}
 //     quad    5 rows: {p0.xyz, D0} {n.xyz, flags} {R.xyz, |R|} {U.xyz, |U|} {motion.xyz, material}
 //             + 2 rows used only when shading: {T.xyz,0} {B.xyz,0}
-//             + 4 rows for the filter, laid out as the SGPR pairs its packed-fp32 instructions take:
-//               {p0.xyz, D0} {n.y, n.z, n.x, flags} {R.x, U.x, R.y, U.y} {R.z, U.z, |R|, |U|}
-//   materials     6 float4 rows per material, read per lane at the closest hit
+//   quad filter   DScene::qfilter, wave-uniform rows of the no-division filter (hrt_kernels.hip quad_filter):
+//               axis-aligned static squares, by normal axis K: {p0_K, centre_I, centre_J, half_I} {half_J, bits, -, -}
+//               all others, laid out as the SGPR pairs the packed-fp32 instructions take:
+//               {p0.xyz, D0} {n.y, n.z, n.x, flags | index << 8} {R.x, U.x, R.y, U.y} {R.z, U.z, |R|, |U|}
+//   materials     8 float4 rows per material, read per lane at the closest hit (rows 6, 7: geometry of its texture / normal map)
 //   meshes        DMesh records (wave-uniform)
 //   kd units      uint4 nodelets (include/hrt.h), refs rebased to the global array
 //   exceptions    irregular triangles (include/hrt.h hrt_tri_exception): {reference leaf box lo, soup slot} {box hi, -}; their
@@ -27,10 +29,9 @@
 
 #include "../../include/hrt.h"
 
-#define HRT_QUAD_ROWS 11
-#define HRT_QUAD_FROW 7   // first of the four rows the no-division filter reads (one s_load_dwordx16)
+#define HRT_QUAD_ROWS 7
 #define HRT_SPHERE_ROWS 2
-#define HRT_MAT_ROWS 6
+#define HRT_MAT_ROWS 8
 #define HRT_TRI_ROWS 5
 #define HRT_QUAD_FLAG_GLASS 1u
 #define HRT_QUAD_FLAG_MOVING 2u
@@ -67,6 +68,11 @@ struct DScene {
     const DImage *images;
     const uint32_t *texels;
     const float4 *lights;  // 2 rows: {pos.xyz, radius} {color.xyz, 0}
+    const float4 *tabs;        // squares | materials | spheres | mesh records in ONE array (what `quads`, `materials`, `spheres`, `meshes` above
+                               // point into): the streaming kernel stages it in LDS for per-lane row fetches (hrt_kernels.hip CtxT)
+    uint32_t tab_quads, tab_mats, tab_spheres, tab_meshes, tab_rows;  // row offsets of the four tables, rows in all
+    const float4 *qfilter;     // rows of the squares' no-division filter: axis-aligned squares by normal axis x, y, z (2 rows each), then the rest (4 rows each)
+    uint32_t qf_n[4];          // squares per section
     const float4 *exceptions;  // 2 rows per entry: {box lo, soup slot of the triangle} {box hi, 0}
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
     uint32_t n_kd_units;

@@ -227,12 +227,11 @@ __device__ __forceinline__ bool walk_some(const CX &cx, const Ray &ray, uint32_t
 // The same with every lane on ITS next mesh at once (per-lane mesh records): lanes that wait for different meshes
 // of a multi-mesh scene walk in the same trips instead of taking turns.  Results cannot differ: a walk depends
 // only on its ray and its mesh.
-typedef const DMesh __attribute__((address_space(1))) *gmesh;
 template <class CX>
 __device__ __forceinline__ bool walk_some_per_lane(const CX &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
     if (CX::exact && (cx.flags & HRT_FLAG_MESH_BRUTE)) return walk_some(cx, ray, parked, w, h, trips);
     const f3 inv = ray_inv<CX::exact>(ray);
-    gmesh meshes = (gmesh)cx.S->meshes;
+    const typename CX::tabmesh meshes = cx.tmesh;
     while (parked != 0u) {
         const uint32_t i = (uint32_t)__builtin_ctz(parked);
         if (!mesh_walk(cx, meshes + i, ray, inv, w, trips)) break;  // out of trips: resume here next visit
@@ -256,6 +255,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
     extern __shared__ uint4 s_units[];
     Ctx cx;
     cx.S = (cscene)R.scene;
+    cx.set_tables((gf4)cx.S->tabs, cx.S);
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
                 ended = true;
             } else {
                 DSP_T(6);
-                const Surface sf = shade(cx.S, p.ray, p.h);
+                const Surface sf = shade(cx, p.ray, p.h);
                 DSP_T(14);
                 f3 direct = mk(0.f, 0.f, 0.f);
                 if (LIGHTS) direct = direct_light(cx, sf, p.ray, p.rng);

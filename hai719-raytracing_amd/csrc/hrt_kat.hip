@@ -75,7 +75,8 @@ extern "C" __global__ void hrt_kat_sphere_kernel(const float4 *rows, const float
 
 // rows: the 11 rows of one square.  out n x 8: hit, t, u, v, normal (Square.h:65-126; oracle_kat_quad), then whether the
 // shipped no-division filter lets the square through (it must whenever hit is set)
-extern "C" __global__ void hrt_kat_quad_kernel(const float4 *rows, const float *__restrict__ rays, uint32_t n, float err_abs, float *__restrict__ out) {
+extern "C" __global__ void hrt_kat_quad_kernel(const float4 *rows, const DScene *filter_scene, const float *__restrict__ rays, uint32_t n, float err_abs,
+                                               float *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Ray ray = kat_ray(rays, i);
@@ -83,8 +84,8 @@ extern "C" __global__ void hrt_kat_quad_kernel(const float4 *rows, const float *
     const bool hit = hrtk::quad_t((gf4)rows, ray, HRT_FLT_MAX, t, u, v);
     const float4 q1 = ld((gf4)rows, 1);
     Ctx cx;
-    cx.S = (cscene) nullptr; cx.lds = (lu4) nullptr; cx.lds_n = 0; cx.err_abs = err_abs; cx.flags = 0; cx.st = nullptr;
-    const uint32_t cand = quad_filter<uint32_t>(cx, ray, (cf4)rows, 1u, HRT_FLT_MAX);
+    cx.S = (cscene)filter_scene; cx.tq = cx.tm = cx.ts = (gf4) nullptr; cx.tmesh = (gmesh) nullptr; cx.lds = (lu4) nullptr; cx.lds_n = 0; cx.err_abs = err_abs; cx.flags = 0; cx.st = nullptr;
+    const uint32_t cand = quad_filter<uint32_t>(cx, ray, HRT_FLT_MAX);  // filter_scene: a DScene whose only content is this square's filter rows
     float *o = out + 8 * (size_t)i;
     o[0] = hit ? 1.f : 0.f; o[1] = hit ? t : 0.f; o[2] = hit ? u : 0.f; o[3] = hit ? v : 0.f;
     o[4] = hit ? q1.x : 0.f; o[5] = hit ? q1.y : 0.f; o[6] = hit ? q1.z : 0.f;

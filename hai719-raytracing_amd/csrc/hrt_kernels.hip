@@ -90,10 +90,14 @@ typedef const DMesh __attribute__((address_space(4))) *cmesh;
 typedef const DScene __attribute__((address_space(4))) *cscene;
 typedef const DCamera __attribute__((address_space(4))) *ccam;
 typedef const DImage __attribute__((address_space(1))) *gimg;
+typedef const v4f __attribute__((address_space(3))) *lf4;         // scene tables staged in LDS (streaming kernel)
+typedef const DMesh __attribute__((address_space(1))) *gmesh;     // per-lane mesh records, global
+typedef const DMesh __attribute__((address_space(3))) *lmesh;     // per-lane mesh records, LDS
 __device__ __forceinline__ float4 ld(cf4 p, uint32_t i) { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float4 ld(gf4 p, uint32_t i) { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint4 ld(gu4 p, uint32_t i) { const v4u v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint4 ld(lu4 p, uint32_t i) { const v4u v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 ld(lf4 p, uint32_t i) { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 
 struct f3 {
     float x, y, z;
@@ -155,9 +159,26 @@ struct Hit {
 // square goes through quad_t in index order, every mesh gate through aabb_gate_exact, shadow rays test every sphere,
 // the camera quotient and the walk's reciprocals are IEEE divisions.  The shipped (EXACT = false) kernels carry none
 // of that code; tests compare the two bit for bit at full frame size.
-template <bool EXACT>
+// LTAB: where a lane finds the small per-object TABLES when it needs a row of ITS OWN object (the square it refines, the
+// material of its hit, its mesh record).  The streaming kernel stages them in LDS (true): a shade there is a chain of
+// dependent row fetches -- object row -> material rows -> image geometry -> texel -- and with the path pool streaming
+// through the CU's 32 KB L1 every hop went to L2 or beyond (measured: 17 k of the 42 k clocks of a square-hit chunk).
+// From LDS only the texel itself is a memory access.  The lane-per-pixel kernels read the same rows from global memory.
+template <bool LTAB> struct TabPtr { typedef gf4 f4; typedef gmesh mesh; };
+template <> struct TabPtr<true> { typedef lf4 f4; typedef lmesh mesh; };
+
+template <bool EXACT, bool LTAB = false>
 struct CtxT {
     static constexpr bool exact = EXACT;
+    typedef typename TabPtr<LTAB>::f4 tab4;
+    typedef typename TabPtr<LTAB>::mesh tabmesh;
+    tab4 tq, tm, ts;   // per-lane rows of squares (HRT_QUAD_ROWS each), materials (HRT_MAT_ROWS), spheres (HRT_SPHERE_ROWS)
+    tabmesh tmesh;     // per-lane mesh records
+    // the tables live in one array (DScene::tabs) in the order squares, materials, spheres, meshes
+    __device__ __forceinline__ void set_tables(tab4 base, cscene S_) {
+        tq = base + S_->tab_quads; tm = base + S_->tab_mats; ts = base + S_->tab_spheres;
+        tmesh = (tabmesh)(base + S_->tab_meshes);
+    }
     cscene S;
     lu4 lds;         // nodelets staged in LDS
     uint32_t lds_n;  // how many
@@ -447,20 +468,70 @@ __device__ __forceinline__ f3 ray_inv(const Ray &ray) {
     return mk(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
 }
 
-// The no-division FILTER over the squares (wave-uniform loop, scalar rows): bit i of the result = square i can possibly
+template <int A>
+__device__ __forceinline__ float cget(f3 v) { return A == 0 ? v.x : (A == 1 ? v.y : v.z); }
+
+// FILTER, axis-aligned squares (most walls of the reference's scenes).  The host recognises a static square whose folded
+// normal is exactly +-e_K and whose edges R, U run along the other two axes (hrt_api.hip classify_aa) and stores it as
+//   r0 {p0_K, centre_I, centre_J, half_I}   r1 {half_J, bits, -, -}      bits: 1 glass, 2 normal points to -K, square index << 8
+// For such a square the reference's t = (D - o.n) / (d.n) IS (p0_K - o_K) / d_K (zeros multiply and add exactly, the sign
+// cancels), and its inside test reads "p_I, p_J within the rectangle" up to rounding -- so the filter needs one
+// subtraction, one multiplication by the ray's reciprocal (computed once per ray), two fma and a handful of compares:
+// 19 VALU instead of the 40 of the general form below, with the same margins (e bounds |p' - p|, see there).
+template <class M, int K, class CX>
+__device__ __forceinline__ void quad_filter_aa(const CX &cx, const Ray &ray, f3 inv, cf4 rows, uint32_t n, float tsure_up, M &cand) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+    const float ok = cget<K>(ray.o), dk = cget<K>(ray.d), ik = cget<K>(inv);
+    const float oi = cget<I>(ray.o), di = cget<I>(ray.d), oj = cget<J>(ray.o), dj = cget<J>(ray.d);
+    auto test = [&](const float4 &r0, const float4 &r1) {
+        const uint32_t bits = __float_as_uint(r1.y);
+        const float ta = (r0.x - ok) * ik;                               // within 3 ulp of the reference's t
+        const float xi = __builtin_fmaf(ta, di, oi) - r0.y, xj = __builtin_fmaf(ta, dj, oj) - r0.z;
+        const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);    // bound on |p' - p|, generous
+        const float dn = __uint_as_float(__float_as_uint(dk) ^ ((bits & 2u) << 30));  // d . n = +-d_K exactly
+        const bool glass = (bits & 1u) != 0u;
+        const bool front = (dn < 0.f) | (glass & (dn > 0.f));  // `|`, `&`: lane masks combined, no short-circuit branches
+        const bool loose = front & (ta >= 9e-6f) & (ta <= tsure_up) & (fabsf(xi) <= r0.w + e) & (fabsf(xj) <= r1.x + e);
+        if (loose) cand |= (M)1 << (bits >> 8);
+    };
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;  // two row sets in ping-pong (see quad_filter)
+    if (n > 0u) { a0 = ld(rows, 0); a1 = ld(rows, 1); }
+    if (n > 1u) { b0 = ld(rows, 2); b1 = ld(rows, 3); }
+    for (uint32_t i = 0; i < n; i += 2u) {
+        test(a0, a1);
+        if (i + 2u < n) { a0 = ld(rows, 2u * (i + 2u)); a1 = ld(rows, 2u * (i + 2u) + 1u); }
+        if (i + 1u < n) {
+            test(b0, b1);
+            if (i + 3u < n) { b0 = ld(rows, 2u * (i + 3u)); b1 = ld(rows, 2u * (i + 3u) + 1u); }
+        }
+    }
+}
+
+// The no-division FILTER over the squares (wave-uniform loops, scalar rows): bit i of the result = square i can possibly
 // be the closest accepted hit (see prims_hit).  M = uint32_t for up to 32 squares (the per-lane mask costs half the VALU
-// work of a 64-bit one), uint64_t for up to 64.
+// work of a 64-bit one), uint64_t for up to 64.  The filter rows live in DScene::qfilter in four sections: axis-aligned
+// squares by normal axis (x, y, z; 2 rows each, quad_filter_aa), then all others (4 rows each, below).
 template <class M, class CX>
-__device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, cf4 qd, uint32_t nq, float tsure) {
+__device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsure) {
     M cand = 0;
-    // Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are already in
-    // flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
-    // load latency overlaps the ~45 VALU instructions of a quad and no row is ever copied (a rolling single-set
+    cscene S = cx.S;
+    cf4 qf = (cf4)S->qfilter;
+    const float tsure_up = tsure * (1.f + 2e-6f);  // the approximate t may exceed the exact one by a few ulp
+    const uint32_t n0 = S->qf_n[0], n1 = S->qf_n[1], n2 = S->qf_n[2], n3 = S->qf_n[3];
+    if (n0 + n1 + n2 != 0u) {
+        const f3 inv = ray_inv<false>(ray);
+        quad_filter_aa<M, 0>(cx, ray, inv, qf, n0, tsure_up, cand);
+        quad_filter_aa<M, 1>(cx, ray, inv, qf + 2u * n0, n1, tsure_up, cand);
+        quad_filter_aa<M, 2>(cx, ray, inv, qf + 2u * (n0 + n1), n2, tsure_up, cand);
+    }
+    // General squares.  Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are
+    // already in flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
+    // load latency overlaps the ~40 VALU instructions of a quad and no row is ever copied (a rolling single-set
     // prefetch costs 16 s_mov per quad, as many issue slots as a third of the filter).
-    // f0 {p0.xyz, D0}  f1 {n.y, n.z, n.x, flags}  f2 {R.x, U.x, R.y, U.y}  f3 {R.z, U.z, |R|, |U|}: the (R, U) and (n.y, n.z)
-    // pairs sit in aligned SGPR pairs, which is how v_pk_mul/fma_f32 take them -- no scalar moves after the load.
-    auto filter = [&](uint32_t i, const float4 &f0, const float4 &f1, const float4 &f2, const float4 &f3) {
-        const uint32_t flags = __float_as_uint(f1.w);
+    // f0 {p0.xyz, D0}  f1 {n.y, n.z, n.x, flags | index << 8}  f2 {R.x, U.x, R.y, U.y}  f3 {R.z, U.z, |R|, |U|}: the (R, U)
+    // and (n.y, n.z) pairs sit in aligned SGPR pairs, which is how v_pk_mul/fma_f32 take them -- no scalar moves after the load.
+    auto filter = [&](const float4 &f0, const float4 &f1, const float4 &f2, const float4 &f3) {
+        const uint32_t flags = __float_as_uint(f1.w), i = flags >> 8;
         if (flags & HRT_QUAD_FLAG_MOVING) { cand |= (M)1 << i; return; }  // uniform branch; the exact path decides
         const float dotRN = ray.d.x * f1.z + ray.d.y * f1.x + ray.d.z * f1.y;  // exact, Vec3.h:48 order: the sign tests are the reference's
         const bool glass = (flags & HRT_QUAD_FLAG_GLASS) != 0u;
@@ -473,32 +544,22 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, cf4 qd, u
         const float x2 = __builtin_fmaf(az, f3.y, __builtin_fmaf(ay, f2.w, ax * f2.y));
         const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);  // bound on |p' - p|, generous
         const float m1 = f3.z * e, m2 = f3.w * e, s1 = f3.z * f3.z, s2 = f3.w * f3.w;
-        const bool loose = front & (ta >= 9e-6f) & (ta * (1.f - 1e-6f) <= tsure) & (x1 >= -m1) & (x1 <= s1 + m1) & (x2 >= -m2) &
-                           (x2 <= s2 + m2);
+        const bool loose = front & (ta >= 9e-6f) & (ta <= tsure_up) & (x1 >= -m1) & (x1 <= s1 + m1) & (x2 >= -m2) & (x2 <= s2 + m2);
         if (loose) cand |= (M)1 << i;
         // (A second, strict test used to shrink `tsure` to the nearest square that is certainly hit, so that squares
         // behind it were not refined.  It cost 11 VALU per square and saved a second refinement on ~5 % of the rays:
         // dropping it is 1-4 % faster on every scene.)
     };
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;
-    cf4 fr = qd + HRT_QUAD_FROW;
-    if (nq > 0u) { a0 = ld(fr, 0); a1 = ld(fr, 1); a2 = ld(fr, 2); a3 = ld(fr, 3); }
-    if (nq > 1u) { b0 = ld(fr, HRT_QUAD_ROWS); b1 = ld(fr, HRT_QUAD_ROWS + 1); b2 = ld(fr, HRT_QUAD_ROWS + 2); b3 = ld(fr, HRT_QUAD_ROWS + 3); }
-#ifdef HRT_FILTER_UNROLL
-#pragma unroll HRT_FILTER_UNROLL
-#endif
-    for (uint32_t i = 0; i < nq; i += 2u) {
-        filter(i, a0, a1, a2, a3);
-        if (i + 2u < nq) {
-            a0 = ld(fr, HRT_QUAD_ROWS * (i + 2u)); a1 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 1);
-            a2 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 2); a3 = ld(fr, HRT_QUAD_ROWS * (i + 2u) + 3);
-        }
-        if (i + 1u < nq) {
-            filter(i + 1u, b0, b1, b2, b3);
-            if (i + 3u < nq) {
-                b0 = ld(fr, HRT_QUAD_ROWS * (i + 3u)); b1 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 1);
-                b2 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 2); b3 = ld(fr, HRT_QUAD_ROWS * (i + 3u) + 3);
-            }
+    cf4 fr = qf + 2u * (n0 + n1 + n2);
+    if (n3 > 0u) { a0 = ld(fr, 0); a1 = ld(fr, 1); a2 = ld(fr, 2); a3 = ld(fr, 3); }
+    if (n3 > 1u) { b0 = ld(fr, 4); b1 = ld(fr, 5); b2 = ld(fr, 6); b3 = ld(fr, 7); }
+    for (uint32_t i = 0; i < n3; i += 2u) {
+        filter(a0, a1, a2, a3);
+        if (i + 2u < n3) { a0 = ld(fr, 4u * (i + 2u)); a1 = ld(fr, 4u * (i + 2u) + 1u); a2 = ld(fr, 4u * (i + 2u) + 2u); a3 = ld(fr, 4u * (i + 2u) + 3u); }
+        if (i + 1u < n3) {
+            filter(b0, b1, b2, b3);
+            if (i + 3u < n3) { b0 = ld(fr, 4u * (i + 3u)); b1 = ld(fr, 4u * (i + 3u) + 1u); b2 = ld(fr, 4u * (i + 3u) + 2u); b3 = ld(fr, 4u * (i + 3u) + 3u); }
         }
     }
     return cand;
@@ -525,9 +586,9 @@ __device__ __forceinline__ Hit prims_hit(const CX &cx, const Ray &ray) {
         // REFINE: only those (usually one per lane) go through the exact Square::intersect arithmetic,
         // in index order with the reference's strict `<`, so the selected hit is the reference's.
         const float tsure = h.t;  // upper bound on the exact t of a hit that certainly exists
-        uint64_t cand = nq <= 32u ? (uint64_t)quad_filter<uint32_t>(cx, ray, qd, nq, tsure) : quad_filter<uint64_t>(cx, ray, qd, nq, tsure);
+        uint64_t cand = nq <= 32u ? (uint64_t)quad_filter<uint32_t>(cx, ray, tsure) : quad_filter<uint64_t>(cx, ray, tsure);
         STAMP(2);
-        gf4 gq = (gf4)S->quads;
+        const typename CX::tab4 gq = cx.tq;
         while (cand) {
             const uint32_t i = (uint32_t)__builtin_ctzll(cand);
             cand &= cand - 1ull;
@@ -638,8 +699,7 @@ __device__ __forceinline__ uint64_t shadow_sphere_groups(cscene S, f3 p, f3 lpos
 template <class CX>
 __device__ __forceinline__ bool shadow_blocked(const CX &cx, const Ray &ray, float tmax, Rng &rng, uint64_t groups, uint32_t gsize) {
     cscene S = cx.S;
-    gf4 sph = (gf4)S->spheres;
-    gf4 mats = (gf4)S->materials;
+    const typename CX::tab4 sph = cx.ts, mats = cx.tm;
     const uint32_t ns = S->n_spheres;
     while (groups) {
         const uint32_t i0 = (uint32_t)__builtin_ctzll(groups) * gsize, i1 = min(i0 + gsize, ns);
@@ -686,40 +746,42 @@ __device__ __forceinline__ bool shadow_blocked(const CX &cx, const Ray &ray, flo
 // rows: 0 {albedo.xyz, transparency} 1 {index_medium, type, texture_type, emissive}
 //       2 {checker1.xyz, scale_x} 3 {checker2.xyz, scale_y} 4 {light_color.xyz, intensity}
 //       5 {image, normal_map, -, -}
-__device__ __forceinline__ uint32_t texel(cscene S, int img, float u, float v, float sx, float sy) {
-    gimg im = (gimg)S->images + img;
-    const int iw = im->w, ih = im->h;
+// geo: row 6 (texture) or 7 (normal map) of the material = {texel offset, w, h, -} as integers, copied there by the host so
+// that no lane has to chase the image table
+__device__ __forceinline__ uint32_t texel(cscene S, const float4 geo, float u, float v, float sx, float sy) {
+    const int iw = (int)__float_as_uint(geo.y), ih = (int)__float_as_uint(geo.z);
     float uu = u * sx, vv = v * sy;
     uu = uu - truncf(uu);            // (float)fmod((double)(u*sx), 1.): exact
     vv = 1.f - (vv - truncf(vv));    // (float)(1 - fmod(...)): one correctly rounded subtraction either way
     const int x = (int)(uu * (float)(iw - 1));
     const int y = (int)(vv * (float)(ih - 1));
-    return ((gu1)S->texels)[im->offset + (uint32_t)(y * iw + x)];
+    return ((gu1)S->texels)[__float_as_uint(geo.x) + (uint32_t)(y * iw + x)];
 }
 __device__ __forceinline__ f3 unit_rgb(uint32_t px) {  // c/255. in double, narrowed (Material.cpp:87)
     return mk(c_u8_lut[px & 255u], c_u8_lut[(px >> 8) & 255u], c_u8_lut[(px >> 16) & 255u]);
 }
 
 // Material::texture, Material.cpp:63-92
-__device__ __forceinline__ f3 mat_texture(cscene S, gf4 m, uint32_t tex_type, f3 color, float u, float v) {
+template <class MP>
+__device__ __forceinline__ f3 mat_texture(cscene S, MP m, uint32_t tex_type, f3 color, float u, float v) {
     if (tex_type == 1u) {
         const float4 c1 = ld(m, 2), c2 = ld(m, 3);
         color = ((int)(u * c1.w) % 2 == (int)(v * c2.w) % 2) ? mk(c1) : mk(c2);
     } else if (tex_type == 2u) {
-        const int img = (int)__float_as_uint(ld(m, 5).x);
-        bool empty = img < 0;
-        if (!empty) { gimg im = (gimg)S->images + img; empty = im->w < 1 || im->h < 1; }
+        const float4 geo = ld(m, 6);
+        const bool empty = (int)__float_as_uint(ld(m, 5).x) < 0 || (int)__float_as_uint(geo.y) < 1 || (int)__float_as_uint(geo.z) < 1;
         if (empty) {
             color = ((int)((double)u * 8.) % 2 == (int)((double)v * 8.) % 2) ? mk(0.f, 0.f, 0.f) : mk(1.f, 0.f, 1.f);
         } else {
-            color = unit_rgb(texel(S, img, u, v, ld(m, 2).w, ld(m, 3).w));
+            color = unit_rgb(texel(S, geo, u, v, ld(m, 2).w, ld(m, 3).w));
         }
     }
     return color;
 }
 
 // Material::emit, Material.cpp:13-24
-__device__ __forceinline__ f3 mat_emit(cscene S, gf4 m, uint32_t tex_type, bool emissive, float u, float v) {
+template <class MP>
+__device__ __forceinline__ f3 mat_emit(cscene S, MP m, uint32_t tex_type, bool emissive, float u, float v) {
     if (!emissive) return mk(0.f, 0.f, 0.f);
     const float4 lc = ld(m, 4);
     f3 c = mk(0.f, 0.f, 0.f);
@@ -741,18 +803,21 @@ struct Surface {
 };
 
 // The hit-dependent part of Scene::rayTraceRecursive, Scene.h:270-300.
-__device__ __forceinline__ Surface shade(cscene S, const Ray &ray, const Hit &h) {
+template <class CX>
+__device__ __forceinline__ Surface shade(const CX &cx, const Ray &ray, const Hit &h) {
+    typedef typename CX::tab4 tab4;
+    cscene S = cx.S;
     Surface sf;
-    gf4 mats = (gf4)S->materials;
+    const tab4 mats = cx.tm;
     const f3 p = ray.o + h.t * ray.d;
     sf.p = p;
     sf.emission = mk(0.f, 0.f, 0.f);
     uint32_t mat_id;
     if (h.kind == 1u) {
-        gf4 sp = (gf4)S->spheres;
+        const tab4 sp = cx.ts;
         const float4 r0 = ld(sp, 2 * h.index), r1 = ld(sp, 2 * h.index + 1);
         mat_id = __float_as_uint(r1.w);
-        gf4 m = mats + HRT_MAT_ROWS * mat_id;
+        const tab4 m = mats + HRT_MAT_ROWS * mat_id;
         const float4 m0 = ld(m, 0), m1 = ld(m, 1);
         const uint32_t tex_type = __float_as_uint(m1.z);
         const bool emissive = __float_as_uint(m1.w) != 0u;
@@ -768,9 +833,9 @@ __device__ __forceinline__ Surface shade(cscene S, const Ray &ray, const Hit &h)
             sf.emission = mat_emit(S, m, tex_type, emissive, u, v);
         }
     } else if (h.kind == 2u) {
-        gf4 q = (gf4)S->quads + HRT_QUAD_ROWS * h.index;
+        const tab4 q = cx.tq + HRT_QUAD_ROWS * h.index;
         mat_id = __float_as_uint(ld(q, 4).w);
-        gf4 m = mats + HRT_MAT_ROWS * mat_id;
+        const tab4 m = mats + HRT_MAT_ROWS * mat_id;
         const float4 m0 = ld(m, 0), m1 = ld(m, 1);
         const uint32_t tex_type = __float_as_uint(m1.z);
         const bool emissive = __float_as_uint(m1.w) != 0u;
@@ -778,14 +843,14 @@ __device__ __forceinline__ Surface shade(cscene S, const Ray &ray, const Hit &h)
         sf.albedo = mat_texture(S, m, tex_type, mk(m0), h.a0, h.a1);
         const int nmap = (int)__float_as_uint(ld(m, 5).y);
         if (nmap >= 0) {  // Material::get_normal, Material.cpp:114-130
-            const uint32_t px = texel(S, nmap, h.a0, h.a1, ld(m, 2).w, ld(m, 3).w);
+            const uint32_t px = texel(S, ld(m, 7), h.a0, h.a1, ld(m, 2).w, ld(m, 3).w);
             const float nx = c_u8_lut[256u + (px & 255u)], ny = c_u8_lut[256u + ((px >> 8) & 255u)],
                         nz = c_u8_lut[256u + ((px >> 16) & 255u)];
             sf.n = normalize(nx * mk(ld(q, 5)) + ny * mk(ld(q, 6)) + nz * sf.n);
         }
         sf.emission = mat_emit(S, m, tex_type, emissive, h.a0, h.a1);
     } else {
-        cmesh M = (cmesh)S->meshes + h.index;  // per-lane index: the compiler falls back to vector loads
+        const typename CX::tabmesh M = cx.tmesh + h.index;  // per-lane mesh record
         mat_id = M->material;
         const float4 m0 = ld(mats, HRT_MAT_ROWS * mat_id);
         gf4 tr = (gf4)S->tris + HRT_TRI_ROWS * h.tri;
@@ -804,7 +869,7 @@ __device__ __forceinline__ Surface shade(cscene S, const Ray &ray, const Hit &h)
             sf.albedo = w0 * mk(ld(colors, vb + vi.x)) + w1 * mk(ld(colors, vb + vi.y)) + w2 * mk(ld(colors, vb + vi.z));
         }
     }
-    gf4 m = mats + HRT_MAT_ROWS * mat_id;
+    const tab4 m = mats + HRT_MAT_ROWS * mat_id;
     const float4 m0 = ld(m, 0), m1 = ld(m, 1);
     sf.transparency = m0.w;
     sf.index_medium = m1.x;
@@ -946,6 +1011,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
     extern __shared__ uint4 s_units[];
     CtxT<EXACT> cx;
     cx.S = (cscene)R.scene;
+    cx.set_tables((gf4)cx.S->tabs, cx.S);
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
@@ -1037,7 +1103,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                     rad = rad + thr * sky(cx.S, ray.d, remaining);
                     ended = true;
                 } else {
-                    const Surface sf = shade(cx.S, ray, h);
+                    const Surface sf = shade(cx, ray, h);
                     STAMP(6);
                     f3 direct = mk(0.f, 0.f, 0.f);
                     if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
@@ -1114,6 +1180,7 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
     const uint32_t x = idx % R.w, y = idx / R.w;
     Ctx cx;
     cx.S = (cscene)R.scene;
+    cx.set_tables((gf4)cx.S->tabs, cx.S);
     cx.lds = (lu4) nullptr;
     cx.lds_n = 0;  // every nodelet from global memory here
     cx.err_abs = R.err_abs;
@@ -1129,7 +1196,7 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
         else if (h.kind) id = (float)h.index;
         o = mk(h.kind ? h.t : 0.f, (float)h.kind, id);
     } else if (h.kind) {
-        const Surface sf = shade(cx.S, ray, h);
+        const Surface sf = shade(cx, ray, h);
         o = which == 1u ? sf.n : (which == 2u ? sf.albedo : sf.emission);
     }
     out[3 * (size_t)idx] = o.x; out[3 * (size_t)idx + 1] = o.y; out[3 * (size_t)idx + 2] = o.z;

@@ -71,14 +71,16 @@ enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_HT, SP_HID, SP_HA0, SP_H
        SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB, SP_RI, SP_REM,  // rewritten by every hit visit: two aligned 16-byte stores
        SP_FIELDS };  // 32 dwords: one 128-byte record
 
-struct SpCtl {           // control block in LDS (20 dwords)
+struct SpCtl {           // control block in LDS (24 dwords)
     uint32_t cT[2], cF[2];   // queue fills, [parity]
     uint32_t cK[4][2];       // closest-hit queues by hit kind (0 miss, 1 sphere, 2 square, 3 mesh), [kind][parity]
     uint32_t cursor;         // chunk cursor of the running cycle
     uint32_t ngen, gen_n0, paths_left;
     uint32_t done, tile, parity, cycles;
     uint32_t gave_up;        // the cycle bound tripped: the whole workgroup leaves the kernel
+    uint32_t pad[3];         // what follows the control block in LDS is read 16 bytes at a time
 };
+static_assert(sizeof(SpCtl) % 16 == 0, "the LDS regions behind the control block must stay 16-byte aligned");
 
 static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
 static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_MAXG * 196 * 4 + 128 <= 160 * 1024,
@@ -96,8 +98,21 @@ struct SpLds {
 #else
 #define SP_AT(field, slot) ((uint32_t)(field) * (uint32_t)HRT_SP_POOL + (slot))
 #endif
-__device__ __forceinline__ float &spf(const SpLds &L, int field, uint32_t slot) { return reinterpret_cast<float *>(L.st)[SP_AT(field, slot)]; }
-__device__ __forceinline__ uint32_t &spu(const SpLds &L, int field, uint32_t slot) { return L.st[SP_AT(field, slot)]; }
+#ifndef HRT_SP_NT
+#define HRT_SP_NT 0        // 1: path records are read and written with the non-temporal hint (they stream through the CU: a record is
+#endif                     //    touched once per visit, 512 KB per workgroup per cycle against a 32 KB L1)
+template <class T>
+struct SpRef {             // one dword of a path record
+    T *p;
+    __device__ __forceinline__ operator T() const { return HRT_SP_NT ? __builtin_nontemporal_load(p) : *p; }
+    __device__ __forceinline__ T operator=(T v) const {
+        if (HRT_SP_NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
+        return v;
+    }
+};
+__device__ __forceinline__ SpRef<float> spf(const SpLds &L, int field, uint32_t slot) { return SpRef<float>{reinterpret_cast<float *>(L.st) + SP_AT(field, slot)}; }
+__device__ __forceinline__ SpRef<uint32_t> spu(const SpLds &L, int field, uint32_t slot) { return SpRef<uint32_t>{L.st + SP_AT(field, slot)}; }
 __device__ __forceinline__ uint16_t *spq(const SpLds &L, int which, uint32_t parity) { return L.q + (2 * which + parity) * HRT_SP_POOL; }
 
 // Wave-aggregated append of `slot` for the lanes with `want`: __ballot + one LDS atomic by the leader.
@@ -170,9 +185,12 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     L.ctl = reinterpret_cast<SpCtl *>(L.q + HRT_SP_NQ * HRT_SP_POOL);
     L.run = reinterpret_cast<float *>(L.ctl + 1);
     uint32_t *tile_xy = reinterpret_cast<uint32_t *>(L.run + HRT_SP_MAXG * 192);  // x0 | y0 << 16 per tile of the unit, ~0: no tile
-    uint4 *s_units = reinterpret_cast<uint4 *>(tile_xy + HRT_SP_MAXG);  // 16-byte aligned: every size above is a multiple of 16
-    CtxT<EXACT> cx;
+    float4 *s_tabs = reinterpret_cast<float4 *>(tile_xy + HRT_SP_MAXG);  // 16-byte aligned: every size above is a multiple of 16
+    CtxT<EXACT, true> cx;
     cx.S = (cscene)R.scene;
+    const uint32_t tab_rows = cx.S->tab_rows;  // the scene's per-object tables: staged once, read per lane from LDS (CtxT)
+    uint4 *s_units = reinterpret_cast<uint4 *>(s_tabs + tab_rows);
+    cx.set_tables((lf4)s_tabs, cx.S);
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
@@ -184,6 +202,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     {
         gu4 g_units = (gu4)cx.S->kd_units;
         for (uint32_t i = tid; i < cx.lds_n; i += HRT_SP_WG) s_units[i] = ld(g_units, i);
+        gf4 g_tabs = (gf4)cx.S->tabs;
+        for (uint32_t i = tid; i < tab_rows; i += HRT_SP_WG) s_tabs[i] = ld(g_tabs, i);
     }
     SpCtl &C = *L.ctl;
     if (tid == 0) {
@@ -199,6 +219,17 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     const uint32_t glog = R.sp_group_log2, G = 1u << glog, upix = 64u << glog;  // tiles and pixels per unit
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
+#ifdef HRT_SP_SEG  // diagnostic build: where a square-hit chunk spends its clocks; every stamp first drains the wave's memory
+                   // counters, so segments are serialised and the whole run is slower than the shipped kernel
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
+    bool seg_on = false;
+#define SEG_START(on) do { seg_on = (on); if (seg_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); seg_last = __builtin_readcyclecounter(); } } while (0)
+#define SEG(k) do { if (seg_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                                  seg[k] += t_ - seg_last; seg_last = t_; } } while (0)
+#else
+#define SEG_START(on) do { } while (0)
+#define SEG(k) do { } while (0)
+#endif
 #ifdef HRT_SP_DEBUG
     unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0;
     unsigned long long dbg_class[6] = {0, 0, 0, 0, 0, 0};  // clocks in T, mesh-hit, sphere-hit, square-hit, miss, G chunks
@@ -326,6 +357,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         const bool act = e < fill;
                         uint32_t slot = 0, kind = 0;
                         bool trace = false, freed = false;  // trace: the path has a new ray to intersect
+                        SEG_START(!is_gen && c >= e1 && c < e2);  // square-hit chunks
                         Ray ray;
                         ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
                         if (act && is_gen) {
@@ -359,6 +391,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             f3 thr = mk(spf(L, SP_TR, slot), spf(L, SP_TG, slot), spf(L, SP_TB, slot));
                             f3 rad = mk(spf(L, SP_RR, slot), spf(L, SP_RG, slot), spf(L, SP_RB, slot));
                             int remaining = (int)spu(L, SP_REM, slot);
+                            asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
+                            SEG(0);  // record loaded
                             bool ended;
                             if (h.kind == 0u) {
                                 rad = rad + thr * sky(cx.S, ray.d, remaining);
@@ -366,12 +400,14 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             } else {
                                 Rng rng;
                                 rng.k0 = spu(L, SP_K0, slot); rng.k1 = spu(L, SP_K1, slot); rng.i = spu(L, SP_RI, slot);
-                                const Surface sf = shade(cx.S, ray, h);
+                                const Surface sf = shade(cx, ray, h);
+                                SEG(1);  // shade: material rows, texel, normal map
                                 f3 direct = mk(0.f, 0.f, 0.f);
                                 if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
                                 rad = rad + thr * (direct + sf.emission);
                                 thr = thr * sf.albedo;
                                 scatter(sf, ray, rng);
+                                SEG(2);  // scatter
                                 --remaining;
                                 ended = (remaining == 0);
                                 if (!ended) {
@@ -383,7 +419,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 }
                             }
                             if (ended) {  // Scene.h:348: the sample's colour, parked until the ordered fold
-                                const uint32_t n = min(spu(L, SP_N, slot), (uint32_t)HRT_SP_UNIT - 1u);  // stays inside the scratch
+                                const uint32_t n = min((uint32_t)spu(L, SP_N, slot), (uint32_t)HRT_SP_UNIT - 1u);  // stays inside the scratch
                                 float *o = scratch + (size_t)n * 3u;
                                 o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
                                 freed = true;
@@ -391,9 +427,12 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         }
                         // spheres + squares + mesh gates for every lane of the chunk that has a new ray
                         bool to_mesh = false;
+                        SEG(3);  // state written back / sample stored
                         if (trace) {
                             const Hit h = prims_hit(cx, ray);
+                            SEG(4);  // spheres + squares
                             const uint32_t pm = has_mesh ? mesh_gates(cx, ray) : 0u;
+                            SEG(5);  // mesh gates
                             sp_store_ray(L, slot, ray);
                             sp_store_hit(L, slot, h, pm);
                             if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
@@ -403,6 +442,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         sp_push(qTo, cTo, trace && to_mesh, slot);
                         sp_push_hit(L, C, parity ^ 1u, trace && !to_mesh, kind, slot);
                         sp_push(qFo, cFo, freed, slot);
+                        SEG(6);  // record stores + queue appends
+#ifdef HRT_SP_SEG
+                        if (seg_on) seg[7] += 1;
+#endif
                     }
 #ifdef HRT_SP_DEBUG
                     dbg_class[dbg_k] += __builtin_readcyclecounter() - dbg_c0;
@@ -448,6 +491,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             R.out_tiles[(size_t)j * 192u + i] = c;
         }
     }
+#ifdef HRT_SP_SEG
+    if (lane == 0 && R.stamps)
+        for (int k = 0; k < 8; ++k) atomicAdd(R.stamps + k, seg[k]);
+#endif
 #ifdef HRT_SP_DEBUG
     if (lane == 0 && R.stamps) {  // per-wave sums: [0] clocks in chunk loops, [1] clocks alive, [2] cycles, [3] chunks, [4] clocks in the serial section
         atomicAdd(R.stamps + 0, dbg_work); atomicAdd(R.stamps + 1, __builtin_readcyclecounter() - dbg_t0);

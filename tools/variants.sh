@@ -6,16 +6,17 @@
 cd "$(dirname "$0")/../hai719-raytracing_amd"
 if [ "$1" = "build" ]; then
   shift
-  rm -f libhrt_var_*.so
+  for f in libhrt_var_*.so; do [ "$f" = libhrt_var_bound.so ] || rm -f "$f"; done
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function $flags -shared -o libhrt_var_$name.so csrc/hrt_api.hip || exit 1
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical $flags -shared -o libhrt_var_$name.so csrc/hrt_api.hip || exit 1
     echo "built libhrt_var_$name.so ($flags)"
   done
 else
   shift
   for lib in libhrt.so libhrt_var_*.so; do
     [ -f $lib ] || continue
+    [ $lib = libhrt_var_bound.so ] && continue
     HRT_LIBNAME=$lib timeout -k 10 300 python3 ../tools/time_only.py "$@" || echo "$lib FAILED"
   done
 fi
