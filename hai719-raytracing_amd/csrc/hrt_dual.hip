@@ -255,7 +255,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
     extern __shared__ uint4 s_units[];
     Ctx cx;
     cx.S = (cscene)R.scene;
-    cx.set_tables((gf4)cx.S->tabs, cx.S);
+    cx.set_tables((gf4)cx.S->tabs, (gf1)c_u8_lut, cx.S);
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
@@ -415,7 +415,7 @@ __device__ __forceinline__ void trace_body_dual(const DRender &R) {
         if (p.live && p.stage == 2u) {
             bool ended;
             if (p.h.kind == 0u) {
-                p.rad = p.rad + p.thr * sky(cx.S, p.ray.d, p.remaining);
+                p.rad = p.rad + p.thr * sky(cx, p.ray.d, p.remaining);
                 ended = true;
             } else {
                 DSP_T(6);

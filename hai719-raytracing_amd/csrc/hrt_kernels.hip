@@ -164,18 +164,22 @@ struct Hit {
 // dependent row fetches -- object row -> material rows -> image geometry -> texel -- and with the path pool streaming
 // through the CU's 32 KB L1 every hop went to L2 or beyond (measured: 17 k of the 42 k clocks of a square-hit chunk).
 // From LDS only the texel itself is a memory access.  The lane-per-pixel kernels read the same rows from global memory.
-template <bool LTAB> struct TabPtr { typedef gf4 f4; typedef gmesh mesh; };
-template <> struct TabPtr<true> { typedef lf4 f4; typedef lmesh mesh; };
+typedef const float __attribute__((address_space(1))) *gf1;
+typedef const float __attribute__((address_space(3))) *lf1;
+template <bool LTAB> struct TabPtr { typedef gf4 f4; typedef gmesh mesh; typedef gf1 f1; };
+template <> struct TabPtr<true> { typedef lf4 f4; typedef lmesh mesh; typedef lf1 f1; };
 
 template <bool EXACT, bool LTAB = false>
 struct CtxT {
     static constexpr bool exact = EXACT;
     typedef typename TabPtr<LTAB>::f4 tab4;
     typedef typename TabPtr<LTAB>::mesh tabmesh;
+    typename TabPtr<LTAB>::f1 lut;  // the u8 -> float tables (c_u8_lut; staged in LDS beside the tables when LTAB)
     tab4 tq, tm, ts;   // per-lane rows of squares (HRT_QUAD_ROWS each), materials (HRT_MAT_ROWS), spheres (HRT_SPHERE_ROWS)
     tabmesh tmesh;     // per-lane mesh records
     // the tables live in one array (DScene::tabs) in the order squares, materials, spheres, meshes
-    __device__ __forceinline__ void set_tables(tab4 base, cscene S_) {
+    __device__ __forceinline__ void set_tables(tab4 base, typename TabPtr<LTAB>::f1 lut_, cscene S_) {
+        lut = lut_;
         tq = base + S_->tab_quads; tm = base + S_->tab_mats; ts = base + S_->tab_spheres;
         tmesh = (tabmesh)(base + S_->tab_meshes);
     }
@@ -748,22 +752,26 @@ __device__ __forceinline__ bool shadow_blocked(const CX &cx, const Ray &ray, flo
 //       5 {image, normal_map, -, -}
 // geo: row 6 (texture) or 7 (normal map) of the material = {texel offset, w, h, -} as integers, copied there by the host so
 // that no lane has to chase the image table
-__device__ __forceinline__ uint32_t texel(cscene S, const float4 geo, float u, float v, float sx, float sy) {
+__device__ __forceinline__ uint32_t texel_index(const float4 geo, float u, float v, float sx, float sy) {
     const int iw = (int)__float_as_uint(geo.y), ih = (int)__float_as_uint(geo.z);
     float uu = u * sx, vv = v * sy;
     uu = uu - truncf(uu);            // (float)fmod((double)(u*sx), 1.): exact
     vv = 1.f - (vv - truncf(vv));    // (float)(1 - fmod(...)): one correctly rounded subtraction either way
     const int x = (int)(uu * (float)(iw - 1));
     const int y = (int)(vv * (float)(ih - 1));
-    return ((gu1)S->texels)[__float_as_uint(geo.x) + (uint32_t)(y * iw + x)];
+    return __float_as_uint(geo.x) + (uint32_t)(y * iw + x);
 }
-__device__ __forceinline__ f3 unit_rgb(uint32_t px) {  // c/255. in double, narrowed (Material.cpp:87)
-    return mk(c_u8_lut[px & 255u], c_u8_lut[(px >> 8) & 255u], c_u8_lut[(px >> 16) & 255u]);
+__device__ __forceinline__ uint32_t texel(cscene S, const float4 geo, float u, float v, float sx, float sy) {
+    return ((gu1)S->texels)[texel_index(geo, u, v, sx, sy)];
+}
+template <class LP>
+__device__ __forceinline__ f3 unit_rgb(LP lut, uint32_t px) {  // c/255. in double, narrowed (Material.cpp:87)
+    return mk(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u]);
 }
 
 // Material::texture, Material.cpp:63-92
-template <class MP>
-__device__ __forceinline__ f3 mat_texture(cscene S, MP m, uint32_t tex_type, f3 color, float u, float v) {
+template <class LP, class MP>
+__device__ __forceinline__ f3 mat_texture(cscene S, LP lut, MP m, uint32_t tex_type, f3 color, float u, float v) {
     if (tex_type == 1u) {
         const float4 c1 = ld(m, 2), c2 = ld(m, 3);
         color = ((int)(u * c1.w) % 2 == (int)(v * c2.w) % 2) ? mk(c1) : mk(c2);
@@ -773,20 +781,20 @@ __device__ __forceinline__ f3 mat_texture(cscene S, MP m, uint32_t tex_type, f3 
         if (empty) {
             color = ((int)((double)u * 8.) % 2 == (int)((double)v * 8.) % 2) ? mk(0.f, 0.f, 0.f) : mk(1.f, 0.f, 1.f);
         } else {
-            color = unit_rgb(texel(S, geo, u, v, ld(m, 2).w, ld(m, 3).w));
+            color = unit_rgb(lut, texel(S, geo, u, v, ld(m, 2).w, ld(m, 3).w));
         }
     }
     return color;
 }
 
 // Material::emit, Material.cpp:13-24
-template <class MP>
-__device__ __forceinline__ f3 mat_emit(cscene S, MP m, uint32_t tex_type, bool emissive, float u, float v) {
+template <class LP, class MP>
+__device__ __forceinline__ f3 mat_emit(cscene S, LP lut, MP m, uint32_t tex_type, bool emissive, float u, float v) {
     if (!emissive) return mk(0.f, 0.f, 0.f);
     const float4 lc = ld(m, 4);
     f3 c = mk(0.f, 0.f, 0.f);
     if (tex_type == 0u) c = mk(lc);
-    else c = mat_texture(S, m, tex_type, c, u, v);
+    else c = mat_texture(S, lut, m, tex_type, c, u, v);
     return c * lc.w;
 }
 
@@ -829,8 +837,8 @@ __device__ __forceinline__ Surface shade(const CX &cx, const Ray &ray, const Hit
             sphere_angles(sf.n, theta, phi);
             const float u = (float)((double)phi / (2 * 3.14159265358979323846));
             const float v = (float)((double)theta / 3.14159265358979323846);
-            sf.albedo = mat_texture(S, m, tex_type, sf.albedo, u, v);
-            sf.emission = mat_emit(S, m, tex_type, emissive, u, v);
+            sf.albedo = mat_texture(S, cx.lut, m, tex_type, sf.albedo, u, v);
+            sf.emission = mat_emit(S, cx.lut, m, tex_type, emissive, u, v);
         }
     } else if (h.kind == 2u) {
         const tab4 q = cx.tq + HRT_QUAD_ROWS * h.index;
@@ -840,15 +848,14 @@ __device__ __forceinline__ Surface shade(const CX &cx, const Ray &ray, const Hit
         const uint32_t tex_type = __float_as_uint(m1.z);
         const bool emissive = __float_as_uint(m1.w) != 0u;
         sf.n = mk(ld(q, 1));
-        sf.albedo = mat_texture(S, m, tex_type, mk(m0), h.a0, h.a1);
+        sf.albedo = mat_texture(S, cx.lut, m, tex_type, mk(m0), h.a0, h.a1);
         const int nmap = (int)__float_as_uint(ld(m, 5).y);
         if (nmap >= 0) {  // Material::get_normal, Material.cpp:114-130
             const uint32_t px = texel(S, ld(m, 7), h.a0, h.a1, ld(m, 2).w, ld(m, 3).w);
-            const float nx = c_u8_lut[256u + (px & 255u)], ny = c_u8_lut[256u + ((px >> 8) & 255u)],
-                        nz = c_u8_lut[256u + ((px >> 16) & 255u)];
+            const float nx = cx.lut[256u + (px & 255u)], ny = cx.lut[256u + ((px >> 8) & 255u)], nz = cx.lut[256u + ((px >> 16) & 255u)];
             sf.n = normalize(nx * mk(ld(q, 5)) + ny * mk(ld(q, 6)) + nz * sf.n);
         }
-        sf.emission = mat_emit(S, m, tex_type, emissive, h.a0, h.a1);
+        sf.emission = mat_emit(S, cx.lut, m, tex_type, emissive, h.a0, h.a1);
     } else {
         const typename CX::tabmesh M = cx.tmesh + h.index;  // per-lane mesh record
         mat_id = M->material;
@@ -915,7 +922,9 @@ __device__ __forceinline__ void scatter(const Surface &sf, Ray &ray, Rng &rng) {
 }
 
 // Scene::skyboxTexture, Scene.h:149-161
-__device__ __forceinline__ f3 sky(cscene S, f3 dir, int remaining) {
+template <class CX>
+__device__ __forceinline__ f3 sky(const CX &cx, f3 dir, int remaining) {
+    cscene S = cx.S;
     const int sb = S->skybox_image;
     if (sb < 0) {
         if (S->dark_sky) return mk(0.f, 0.f, 0.f);
@@ -929,7 +938,7 @@ __device__ __forceinline__ f3 sky(cscene S, f3 dir, int remaining) {
     int x = (int)(u * (float)iw), y = (int)(v * (float)ih);
     x = min(x, iw - 1);  // the reference reads out of bounds at u == 1; clamped (as the oracle)
     y = min(y, ih - 1);
-    return unit_rgb(((gu1)S->texels)[im->offset + (uint32_t)(y * iw + x)]) * (float)remaining;
+    return unit_rgb(cx.lut, ((gu1)S->texels)[im->offset + (uint32_t)(y * iw + x)]) * (float)remaining;
 }
 
 // Direct light with soft shadows, Scene.h:305-334.
@@ -1011,7 +1020,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
     extern __shared__ uint4 s_units[];
     CtxT<EXACT> cx;
     cx.S = (cscene)R.scene;
-    cx.set_tables((gf4)cx.S->tabs, cx.S);
+    cx.set_tables((gf4)cx.S->tabs, (gf1)c_u8_lut, cx.S);
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
@@ -1100,7 +1109,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
             if (live && stage == 2u) {
                 bool ended;
                 if (h.kind == 0u) {
-                    rad = rad + thr * sky(cx.S, ray.d, remaining);
+                    rad = rad + thr * sky(cx, ray.d, remaining);
                     ended = true;
                 } else {
                     const Surface sf = shade(cx, ray, h);
@@ -1180,7 +1189,7 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
     const uint32_t x = idx % R.w, y = idx / R.w;
     Ctx cx;
     cx.S = (cscene)R.scene;
-    cx.set_tables((gf4)cx.S->tabs, cx.S);
+    cx.set_tables((gf4)cx.S->tabs, (gf1)c_u8_lut, cx.S);
     cx.lds = (lu4) nullptr;
     cx.lds_n = 0;  // every nodelet from global memory here
     cx.err_abs = R.err_abs;

@@ -185,12 +185,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     L.ctl = reinterpret_cast<SpCtl *>(L.q + HRT_SP_NQ * HRT_SP_POOL);
     L.run = reinterpret_cast<float *>(L.ctl + 1);
     uint32_t *tile_xy = reinterpret_cast<uint32_t *>(L.run + HRT_SP_MAXG * 192);  // x0 | y0 << 16 per tile of the unit, ~0: no tile
-    float4 *s_tabs = reinterpret_cast<float4 *>(tile_xy + HRT_SP_MAXG);  // 16-byte aligned: every size above is a multiple of 16
+    float *s_lut = reinterpret_cast<float *>(tile_xy + HRT_SP_MAXG);     // the u8 -> float tables (512 floats)
+    float4 *s_tabs = reinterpret_cast<float4 *>(s_lut + 512);            // 16-byte aligned: every size above is a multiple of 16
     CtxT<EXACT, true> cx;
     cx.S = (cscene)R.scene;
     const uint32_t tab_rows = cx.S->tab_rows;  // the scene's per-object tables: staged once, read per lane from LDS (CtxT)
     uint4 *s_units = reinterpret_cast<uint4 *>(s_tabs + tab_rows);
-    cx.set_tables((lf4)s_tabs, cx.S);
+    cx.set_tables((lf4)s_tabs, (lf1)s_lut, cx.S);
     cx.lds = (lu4)s_units;
     cx.lds_n = R.lds_units;
     cx.err_abs = R.err_abs;
@@ -204,6 +205,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         for (uint32_t i = tid; i < cx.lds_n; i += HRT_SP_WG) s_units[i] = ld(g_units, i);
         gf4 g_tabs = (gf4)cx.S->tabs;
         for (uint32_t i = tid; i < tab_rows; i += HRT_SP_WG) s_tabs[i] = ld(g_tabs, i);
+        if (tid < 512u) s_lut[tid] = c_u8_lut[tid];
     }
     SpCtl &C = *L.ctl;
     if (tid == 0) {
@@ -319,20 +321,30 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         // ---------------- T: mesh walk
                         const uint32_t e = c * 64u + lane;
                         const bool act = e < cTin;
-                        uint32_t slot = 0, kind = 0;
+                        uint32_t slot = 0, kind = 0, pm = 0, ref_in = HRT_KD_NIL, pm_before = 0;
                         bool walked = false;
+                        Ray ray;
+                        ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
+                        Hit h;
+                        h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
+                        Walk w;
+                        w.ref = HRT_KD_NIL; w.t_entry = 0.f; w.kk = 0xFFFFu; w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
                         if (act) {
                             slot = qTi[e] & (HRT_SP_POOL - 1u);
-                            const Ray ray = sp_load_ray(L, slot);
-                            Hit h = sp_load_hit(L, slot);
-                            uint32_t pm = spu(L, SP_PM, slot);
-                            Walk w;
+                            ray = sp_load_ray(L, slot);
+                            h = sp_load_hit(L, slot);
+                            pm = spu(L, SP_PM, slot);
+                            pm_before = pm;
                             w.ref = spu(L, SP_WREF, slot); w.t_entry = spf(L, SP_WTE, slot); w.kk = spu(L, SP_WKK, slot);
-                            const uint32_t ref_in = w.ref;
+                            ref_in = w.ref;
                             w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
                             w.bv = spf(L, SP_WBV, slot);
-                            const uint32_t pm_in = pm;
+                        }
+                        if (act) {
                             walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
+                        }
+                        if (act) {
+                            const uint32_t pm_in = pm_before;
                             if (pm != pm_in) sp_store_hit(L, slot, h, pm);  // a mesh was finished: the best hit may have changed
                             if (!walked) {  // the state of the walk in progress
                                 spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
@@ -391,11 +403,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             f3 thr = mk(spf(L, SP_TR, slot), spf(L, SP_TG, slot), spf(L, SP_TB, slot));
                             f3 rad = mk(spf(L, SP_RR, slot), spf(L, SP_RG, slot), spf(L, SP_RB, slot));
                             int remaining = (int)spu(L, SP_REM, slot);
+#ifdef HRT_SP_SEG
                             asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
+#endif
                             SEG(0);  // record loaded
                             bool ended;
                             if (h.kind == 0u) {
-                                rad = rad + thr * sky(cx.S, ray.d, remaining);
+                                rad = rad + thr * sky(cx, ray.d, remaining);
                                 ended = true;
                             } else {
                                 Rng rng;
@@ -428,16 +442,21 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         // spheres + squares + mesh gates for every lane of the chunk that has a new ray
                         bool to_mesh = false;
                         SEG(3);  // state written back / sample stored
+                        Hit hn;
+                        hn.kind = 0; hn.index = 0; hn.t = HRT_FLT_MAX; hn.tri = 0; hn.a0 = 0.f; hn.a1 = 0.f;
+                        uint32_t pmn = 0;
                         if (trace) {
-                            const Hit h = prims_hit(cx, ray);
+                            hn = prims_hit(cx, ray);
                             SEG(4);  // spheres + squares
-                            const uint32_t pm = has_mesh ? mesh_gates(cx, ray) : 0u;
+                            pmn = has_mesh ? mesh_gates(cx, ray) : 0u;
                             SEG(5);  // mesh gates
+                        }
+                        if (trace) {
                             sp_store_ray(L, slot, ray);
-                            sp_store_hit(L, slot, h, pm);
+                            sp_store_hit(L, slot, hn, pmn);
                             if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
-                            to_mesh = pm != 0u;
-                            kind = h.kind;
+                            to_mesh = pmn != 0u;
+                            kind = hn.kind;
                         }
                         sp_push(qTo, cTo, trace && to_mesh, slot);
                         sp_push_hit(L, C, parity ^ 1u, trace && !to_mesh, kind, slot);

@@ -1,5 +1,6 @@
 #include "scene.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -449,8 +450,9 @@ std::unique_ptr<FlatScene> Scene::flatten() const {
         const float amin[3] = {boxed.aabb.p0[0], boxed.aabb.p0[1], boxed.aabb.p0[2]}, amax[3] = {boxed.aabb.p1[0], boxed.aabb.p1[1], boxed.aabb.p1[2]};
         // What the reference's own tree does to this mesh that no other tree would reproduce (ref_tree.h): dropped
         // triangles and slivers stay out of the SAH tree and travel as (triangle, reference leaf box) exceptions.
-        f.ref_analysis[mi] = analyse_reference_tree(pos.data(), (uint32_t)m.vertices.size(), idx.data(), (uint32_t)m.triangles.size(),
-                                                    amin, amax);
+        if (std::getenv("HRT_ABL_NO_EXCEPTIONS")) f.ref_analysis[mi].irregular.assign(m.triangles.size(), 0);  // timing experiments only: not parity-safe
+        else f.ref_analysis[mi] = analyse_reference_tree(pos.data(), (uint32_t)m.vertices.size(), idx.data(), (uint32_t)m.triangles.size(),
+                                                         amin, amax);
         f.trees[mi] = build_flat_kdtree(scaled.data(), (uint32_t)m.vertices.size(), idx.data(),
                                         (uint32_t)m.triangles.size(), kd_params, f.ref_analysis[mi].irregular.data());
         o.n_vertices = (uint32_t)m.vertices.size();
