@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -512,29 +514,83 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         }
         dm.tri_base = tri_base;
         dm.n_soup = M.n_leaf_tris;
-        // irregular triangles: their rows go behind the leaf-ordered part (no leaf lists them), one slot per triangle
+        // Irregular triangles (include/hrt.h hrt_tri_exception): grouped by reference leaf box.  Each distinct box becomes a
+        // leaf entry {box lo, first soup slot} {box hi, count} whose triangles' rows sit contiguously behind the mesh's
+        // leaf-ordered soup (a triangle held by several boxes is folded once per box: a box hit then reads one run of rows);
+        // a bounding hierarchy over the boxes, threaded depth-first ({lo', HRT_EXC_INNER} {hi', skip}), lets a ray that
+        // passes none of them leave after one test.  Inner boxes are padded: they only cull, the leaf boxes decide.
         dm.exc_base = (uint32_t)(exceptions.size() / 2);
-        dm.n_exc = M.n_exceptions;
-        {
-            std::unordered_map<uint32_t, uint32_t> slots;  // triangle id -> soup slot (each irregular triangle folded once)
-            for (uint32_t k = 0; k < M.n_exceptions; ++k) {
-                const hrt_tri_exception &e = M.exceptions[k];
-                uint32_t word = HRT_EXC_INNER, skip = k + 1u;
-                if (e.triangle == HRT_EXC_INNER) {
-                    if (e.skip <= k || e.skip > M.n_exceptions) return fail(HRT_ERR_INVALID, "exception list: bad skip link");
-                    skip = e.skip;
-                } else {
-                    if (e.triangle >= M.n_triangles) return fail(HRT_ERR_INVALID, "exception triangle id out of range");
-                    auto it = slots.find(e.triangle);
-                    if (it == slots.end()) {
-                        it = slots.emplace(e.triangle, (uint32_t)(tris.size() / HRT_TRI_ROWS)).first;
-                        push_triangle(e.triangle);
-                    }
-                    word = it->second;
+        dm.n_exc = 0;
+        if (M.n_exceptions) {
+            struct Group { float lo[3], hi[3]; std::vector<uint32_t> tris; };
+            std::vector<Group> groups;
+            {
+                std::vector<uint32_t> order(M.n_exceptions);
+                for (uint32_t k = 0; k < M.n_exceptions; ++k) {
+                    if (M.exceptions[k].triangle >= M.n_triangles) return fail(HRT_ERR_INVALID, "exception triangle id out of range");
+                    order[k] = k;
                 }
-                exceptions.push_back(make_float4(e.box_min[0], e.box_min[1], e.box_min[2], as_float(word)));
-                exceptions.push_back(make_float4(e.box_max[0], e.box_max[1], e.box_max[2], as_float(skip)));
+                auto box_less = [&](uint32_t x, uint32_t y) { return std::memcmp(M.exceptions[x].box_min, M.exceptions[y].box_min, 24) < 0; };  // box_min, box_max are adjacent
+                static_assert(offsetof(hrt_tri_exception, box_max) == offsetof(hrt_tri_exception, box_min) + 12, "box_min and box_max are contiguous");
+                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return box_less(x, y) || (!box_less(y, x) && M.exceptions[x].triangle < M.exceptions[y].triangle); });
+                for (uint32_t k : order) {
+                    const hrt_tri_exception &e = M.exceptions[k];
+                    if (groups.empty() || std::memcmp(groups.back().lo, e.box_min, 12) != 0 || std::memcmp(groups.back().hi, e.box_max, 12) != 0) {
+                        groups.emplace_back();
+                        std::memcpy(groups.back().lo, e.box_min, 12);
+                        std::memcpy(groups.back().hi, e.box_max, 12);
+                    }
+                    if (groups.back().tris.empty() || groups.back().tris.back() != e.triangle) groups.back().tris.push_back(e.triangle);
+                }
             }
+            const size_t first_entry = exceptions.size() / 2;
+            struct Emit {
+                std::vector<Group> &g;
+                std::vector<float4> &out;
+                std::vector<float4> &tris;
+                const std::function<void(uint32_t)> &push_triangle;
+                size_t first_entry;
+                void run(size_t lo, size_t hi) {
+                    if (hi - lo == 1) {
+                        const Group &b = g[lo];
+                        const uint32_t first = (uint32_t)(tris.size() / HRT_TRI_ROWS);
+                        for (uint32_t t : b.tris) push_triangle(t);
+                        out.push_back(make_float4(b.lo[0], b.lo[1], b.lo[2], as_float(first)));
+                        out.push_back(make_float4(b.hi[0], b.hi[1], b.hi[2], as_float((uint32_t)b.tris.size())));
+                        return;
+                    }
+                    float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (size_t i = lo; i < hi; ++i)
+                        for (int a = 0; a < 3; ++a) {
+                            bmin[a] = std::min(bmin[a], g[i].lo[a]); bmax[a] = std::max(bmax[a], g[i].hi[a]);
+                            const float c = 0.5f * (g[i].lo[a] + g[i].hi[a]);
+                            cmin[a] = std::min(cmin[a], c); cmax[a] = std::max(cmax[a], c);
+                        }
+                    int axis = 0;
+                    for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+                    const size_t mid = lo + (hi - lo) / 2;
+                    std::nth_element(g.begin() + lo, g.begin() + mid, g.begin() + hi, [axis](const Group &x, const Group &y) {
+                        const float cx = x.lo[axis] + x.hi[axis], cy = y.lo[axis] + y.hi[axis];
+                        return cx < cy || (cx == cy && std::memcmp(x.lo, y.lo, 12) < 0);
+                    });
+                    const size_t self = out.size();
+                    float pmin[3], pmax[3];
+                    for (int a = 0; a < 3; ++a) {
+                        const float pad = 1e-4f * std::max(1.f, std::max(std::fabs(bmin[a]), std::fabs(bmax[a])));
+                        pmin[a] = bmin[a] - pad; pmax[a] = bmax[a] + pad;
+                    }
+                    out.push_back(make_float4(pmin[0], pmin[1], pmin[2], as_float(HRT_EXC_INNER)));
+                    out.push_back(make_float4(pmax[0], pmax[1], pmax[2], 0.f));
+                    run(lo, mid);
+                    run(mid, hi);
+                    out[self + 1].w = as_float((uint32_t)(out.size() / 2 - first_entry));  // skip: first entry behind this subtree, relative to the mesh's list
+                }
+            };
+            const std::function<void(uint32_t)> pt = push_triangle;
+            Emit em{groups, exceptions, tris, pt, first_entry};
+            em.run(0, groups.size());
+            dm.n_exc = (uint32_t)(exceptions.size() / 2 - first_entry);
         }
         dm.material = (uint32_t)M.material;
         dm.color_type = HRT_COLOR_NONE;
@@ -579,6 +635,9 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         d.tab_meshes = (uint32_t)tabs.size();
         tabs.resize(tabs.size() + meshes.size() * (sizeof(DMesh) / sizeof(float4)));
         if (!meshes.empty()) std::memcpy(&tabs[d.tab_meshes], meshes.data(), meshes.size() * sizeof(DMesh));
+        d.tab_exc = (uint32_t)tabs.size();
+        d.exc_in_tabs = exceptions.size() <= 1536u ? 1u : 0u;  // short exception lists ride along (24 KB at most)
+        if (d.exc_in_tabs) tabs.insert(tabs.end(), exceptions.begin(), exceptions.end());
         d.tab_rows = (uint32_t)tabs.size();
         UP(tabs, tabs, float4)
         d.quads = d.tabs + d.tab_quads;

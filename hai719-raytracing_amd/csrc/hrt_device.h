@@ -16,8 +16,9 @@
 //   materials     8 float4 rows per material, read per lane at the closest hit (rows 6, 7: geometry of its texture / normal map)
 //   meshes        DMesh records (wave-uniform)
 //   kd units      uint4 nodelets (include/hrt.h), refs rebased to the global array
-//   exceptions    irregular triangles (include/hrt.h hrt_tri_exception): {reference leaf box lo, soup slot} {box hi, -}; their
-//                 rows sit behind the mesh's leaf-ordered part of the soup
+//   exceptions    irregular triangles (include/hrt.h hrt_tri_exception) by distinct reference leaf box: leaf entry {box lo, first soup
+//                 slot} {box hi, count} (the triangles' rows sit contiguously behind the mesh's leaf-ordered soup), bounding entry
+//                 {lo, HRT_EXC_INNER} {hi, skip}, threaded depth-first
 //   triangles     leaf-ordered soup, 5 float4 rows: {c0, id} {e1, d00} {e2, d01} {n, D} {d11, denom, -, -}
 //                 (Triangle.h:32-37, 62-75 constants folded on the host in the reference's arithmetic)
 //   colours       float4 per face / per vertex (+ uint4 vertex ids per triangle)
@@ -33,6 +34,7 @@
 #define HRT_SPHERE_ROWS 2
 #define HRT_MAT_ROWS 8
 #define HRT_TRI_ROWS 5
+#define HRT_EXC_INNER 0xFFFFFFFFu  // first word of a bounding entry of a mesh's exception list (DScene::exceptions)
 #define HRT_QUAD_FLAG_GLASS 1u
 #define HRT_QUAD_FLAG_MOVING 2u
 
@@ -70,10 +72,11 @@ struct DScene {
     const float4 *lights;  // 2 rows: {pos.xyz, radius} {color.xyz, 0}
     const float4 *tabs;        // squares | materials | spheres | mesh records in ONE array (what `quads`, `materials`, `spheres`, `meshes` above
                                // point into): the streaming kernel stages it in LDS for per-lane row fetches (hrt_kernels.hip CtxT)
-    uint32_t tab_quads, tab_mats, tab_spheres, tab_meshes, tab_rows;  // row offsets of the four tables, rows in all
+    uint32_t tab_quads, tab_mats, tab_spheres, tab_meshes, tab_exc, tab_rows;  // row offsets of the tables, rows in all
+    uint32_t exc_in_tabs;      // 1: the meshes' exception lists are short (<= 512 rows) and sit in `tabs` at tab_exc; 0: in `exceptions`
     const float4 *qfilter;     // rows of the squares' no-division filter: axis-aligned squares by normal axis x, y, z (2 rows each), then the rest (4 rows each)
     uint32_t qf_n[4];          // squares per section
-    const float4 *exceptions;  // 2 rows per entry: {box lo, soup slot of the triangle} {box hi, 0}
+    const float4 *exceptions;  // 2 rows per entry (see above)
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
     uint32_t n_kd_units;
     int32_t dark_sky, skybox_image;

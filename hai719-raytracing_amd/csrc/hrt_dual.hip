@@ -134,7 +134,7 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
         t0 = (M->kd_lo[2] - ray.o.z) * inv.z; t1 = (M->kd_hi[2] - ray.o.z) * inv.z;
         t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
         w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
-        (void)mesh_exceptions<CX::exact>(cx.S, M, ray, inv, w.best_t, w.best_tri, w.bu, w.bv);  // irregular triangles first (not in the tree)
+        (void)mesh_exceptions<CX::exact>(cx, M, ray, inv, w.best_t, w.best_tri, w.bu, w.bv);  // irregular triangles first (not in the tree)
         if (!(t_entry <= t_scene_exit)) return true;
         w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
     }

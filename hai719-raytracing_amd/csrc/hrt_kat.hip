@@ -84,7 +84,7 @@ extern "C" __global__ void hrt_kat_quad_kernel(const float4 *rows, const DScene 
     const bool hit = hrtk::quad_t((gf4)rows, ray, HRT_FLT_MAX, t, u, v);
     const float4 q1 = ld((gf4)rows, 1);
     Ctx cx;
-    cx.S = (cscene)filter_scene; cx.tq = cx.tm = cx.ts = (gf4) nullptr; cx.tmesh = (gmesh) nullptr; cx.lut = (gf1) nullptr; cx.lds = (lu4) nullptr; cx.lds_n = 0; cx.err_abs = err_abs; cx.flags = 0; cx.st = nullptr;
+    cx.S = (cscene)filter_scene; cx.tq = cx.tm = cx.ts = cx.texc = (gf4) nullptr; cx.tmesh = (gmesh) nullptr; cx.lut = (gf1) nullptr; cx.lds = (lu4) nullptr; cx.lds_n = 0; cx.err_abs = err_abs; cx.flags = 0; cx.st = nullptr;
     const uint32_t cand = quad_filter<uint32_t>(cx, ray, HRT_FLT_MAX);  // filter_scene: a DScene whose only content is this square's filter rows
     float *o = out + 8 * (size_t)i;
     o[0] = hit ? 1.f : 0.f; o[1] = hit ? t : 0.f; o[2] = hit ? u : 0.f; o[3] = hit ? v : 0.f;

@@ -175,12 +175,13 @@ struct CtxT {
     typedef typename TabPtr<LTAB>::f4 tab4;
     typedef typename TabPtr<LTAB>::mesh tabmesh;
     typename TabPtr<LTAB>::f1 lut;  // the u8 -> float tables (c_u8_lut; staged in LDS beside the tables when LTAB)
+    tab4 texc;         // exception lists of the meshes when they are short enough to travel with the tables (DScene::exc_in_tabs)
     tab4 tq, tm, ts;   // per-lane rows of squares (HRT_QUAD_ROWS each), materials (HRT_MAT_ROWS), spheres (HRT_SPHERE_ROWS)
     tabmesh tmesh;     // per-lane mesh records
     // the tables live in one array (DScene::tabs) in the order squares, materials, spheres, meshes
     __device__ __forceinline__ void set_tables(tab4 base, typename TabPtr<LTAB>::f1 lut_, cscene S_) {
         lut = lut_;
-        tq = base + S_->tab_quads; tm = base + S_->tab_mats; ts = base + S_->tab_spheres;
+        tq = base + S_->tab_quads; tm = base + S_->tab_mats; ts = base + S_->tab_spheres; texc = base + S_->tab_exc;
         tmesh = (tabmesh)(base + S_->tab_meshes);
     }
     cscene S;
@@ -323,8 +324,12 @@ __device__ __forceinline__ uint4 kd_fetch(gu4 g, const CX &cx, uint32_t i) {
 // One triangle of the soup against the ray: Triangle::getIntersection (Triangle.h:77-126) with the constructor's and
 // computeBarycentricCoordinates' constants folded on the host (rows 0 {c0, id} 1 {e1, d00} 2 {e2, d01} 3 {n, D} 4 {d11, denom}),
 // then the leaf's strict `<` against the best so far (KDTree.cpp:44).  True when this triangle became the best.
+__device__ __forceinline__ bool tri_test_r3(gf4 tr, const float4 r3, const Ray &ray, float &best_t, float &bu, float &bv);
 __device__ __forceinline__ bool tri_test(gf4 tr, const Ray &ray, float &best_t, float &bu, float &bv) {
-    const float4 r3 = ld(tr, 3);
+    return tri_test_r3(tr, ld(tr, 3), ray, best_t, bu, bv);
+}
+// the same with row 3 {n, D} already in registers (a caller that tests a run of triangles requests several ahead)
+__device__ __forceinline__ bool tri_test_r3(gf4 tr, const float4 r3, const Ray &ray, float &best_t, float &bu, float &bv) {
     const f3 n = mk(r3);
     const float dotRN = dot(ray.d, n);
     if (!(dotRN < 0.f)) return false;                     // :80-91 parallel / back-facing (NaN: no hit)
@@ -345,28 +350,42 @@ __device__ __forceinline__ bool tri_test(gf4 tr, const Ray &ray, float &best_t, 
 // drops in part of its tree, and slivers whose barycentric test accepts phantom points.  They are not in the rope tree;
 // each is tested exactly when the reference would test it -- when the ray passes the box of a reference leaf that holds
 // it (KDTree.cpp:32-46 with AABB.h:48-65; EXACT: the fp64 form only, else the fp32 filter in front of it).
-template <bool EXACT, class MP>
-__device__ __forceinline__ bool mesh_exceptions(cscene S, MP M, const Ray &ray, f3 inv, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
+template <bool EXACT, class EP, class MP>
+__device__ __forceinline__ bool mesh_exceptions_walk(cscene S, EP ex_all, MP M, const Ray &ray, f3 inv, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
     const uint32_t n = M->n_exc;
     bool found = false;
-    if (n != 0u) {
-        gf4 ex = (gf4)S->exceptions + 2u * M->exc_base;
-        gf4 tris = (gf4)S->tris;
-        // rows {box lo, soup slot | HRT_EXC_INNER} {box hi, skip}: a bounding hierarchy threaded depth-first (include/hrt.h)
-        for (uint32_t i = 0; i < n;) {
-            const float4 lo = ld(ex, 2u * i), hi = ld(ex, 2u * i + 1u);
-            const uint32_t slot = __float_as_uint(lo.w);
-            GateBox b;
-            b.l[0] = lo.x; b.l[1] = lo.y; b.l[2] = lo.z; b.h[0] = hi.x; b.h[1] = hi.y; b.h[2] = hi.z;
-            ++i;
-            if (slot == HRT_EXC_INNER) {  // bounds of a subtree: only culls (never in the proof builds)
-                if (!EXACT && gate_filter(b, ray, inv) < 0) i = __float_as_uint(hi.w);
-            } else if (mesh_gate_box<EXACT>(b, ray, inv)) {
-                if (tri_test(tris + HRT_TRI_ROWS * slot, ray, best_t, bu, bv)) { best_tri = slot; found = true; }
+    const EP ex = ex_all + 2u * M->exc_base;
+    gf4 tris = (gf4)S->tris;
+    // entries {box lo, first soup slot | HRT_EXC_INNER} {box hi, count | skip}: the distinct reference leaf boxes under a
+    // bounding hierarchy threaded depth-first (hrt_api.hip scene_create_impl)
+    for (uint32_t i = 0; i < n;) {
+        const float4 lo = ld(ex, 2u * i), hi = ld(ex, 2u * i + 1u);
+        const uint32_t first = __float_as_uint(lo.w), cnt = __float_as_uint(hi.w);
+        GateBox b;
+        b.l[0] = lo.x; b.l[1] = lo.y; b.l[2] = lo.z; b.h[0] = hi.x; b.h[1] = hi.y; b.h[2] = hi.z;
+        ++i;
+        if (first == HRT_EXC_INNER) {  // bounds of a subtree: only culls (never in the proof builds)
+            if (!EXACT && gate_filter(b, ray, inv) < 0) i = cnt;
+        } else if (mesh_gate_box<EXACT>(b, ray, inv)) {  // the ray passes this reference leaf: its irregular triangles are tested
+            for (uint32_t k = 0; k < cnt; k += 4u) {  // four plane rows in flight: a run can be long (a leaf the reference's builder gave up on)
+                float4 r3[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) r3[j] = ld(tris + HRT_TRI_ROWS * (first + min(k + j, cnt - 1u)), 3);
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                    if (k + j < cnt && tri_test_r3(tris + HRT_TRI_ROWS * (first + k + j), r3[j], ray, best_t, bu, bv)) { best_tri = first + k + j; found = true; }
             }
         }
     }
     return found;
+}
+// Short lists travel with the per-object tables (staged in LDS by the streaming kernel: the walk through the list is a
+// chain of dependent row fetches); long ones (a mesh the reference's builder mangles badly) stay in global memory.
+template <bool EXACT, class CX, class MP>
+__device__ __forceinline__ bool mesh_exceptions(const CX &cx, MP M, const Ray &ray, f3 inv, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
+    if (M->n_exc == 0u) return false;
+    if (cx.S->exc_in_tabs) return mesh_exceptions_walk<EXACT>(cx.S, cx.texc, M, ray, inv, best_t, best_tri, bu, bv);
+    return mesh_exceptions_walk<EXACT>(cx.S, (gf4)cx.S->exceptions, M, ray, inv, best_t, best_tri, bu, bv);
 }
 
 // HRT_FLAG_MESH_BRUTE (exact builds only): every triangle of the mesh's leaf-ordered soup, no tree -- the device-side
@@ -378,7 +397,7 @@ __device__ __forceinline__ bool mesh_brute(const CX &cx, cmesh M, const Ray &ray
     gf4 tris = (gf4)cx.S->tris;
     const uint32_t first = M->tri_base, cnt = M->n_soup;
     best_t = HRT_FLT_MAX;
-    bool found = mesh_exceptions<true>(cx.S, M, ray, mk(0.f, 0.f, 0.f), best_t, best_tri, bu, bv);
+    bool found = mesh_exceptions<true>(cx, M, ray, mk(0.f, 0.f, 0.f), best_t, best_tri, bu, bv);
     for (uint32_t k = 0; k < cnt; ++k)
         if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, best_t, bu, bv)) { best_tri = first + k; found = true; }
     return found;
@@ -402,7 +421,7 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
         t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
     }
     best_t = HRT_FLT_MAX;
-    bool found = mesh_exceptions<CX::exact>(cx.S, M, ray, inv, best_t, best_tri, bu, bv);
+    bool found = mesh_exceptions<CX::exact>(cx, M, ray, inv, best_t, best_tri, bu, bv);
     if (!(t_entry <= t_scene_exit)) return found;
     gu4 g_units = (gu4)cx.S->kd_units;
     gf4 tris = (gf4)cx.S->tris;

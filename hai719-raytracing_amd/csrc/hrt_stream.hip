@@ -221,6 +221,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     const uint32_t glog = R.sp_group_log2, G = 1u << glog, upix = 64u << glog;  // tiles and pixels per unit
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
+#ifndef HRT_SP_SEG_KIND
+#define HRT_SP_SEG_KIND 1  // which chunk class the diagnostic build stamps: 1 square hits, 2 T (KD walk)
+#endif
 #ifdef HRT_SP_SEG  // diagnostic build: where a square-hit chunk spends its clocks; every stamp first drains the wave's memory
                    // counters, so segments are serialised and the whole run is slower than the shipped kernel
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
@@ -329,6 +332,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
                         Walk w;
                         w.ref = HRT_KD_NIL; w.t_entry = 0.f; w.kk = 0xFFFFu; w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
+                        SEG_START(HRT_SP_SEG_KIND == 2);
                         if (act) {
                             slot = qTi[e] & (HRT_SP_POOL - 1u);
                             ray = sp_load_ray(L, slot);
@@ -340,9 +344,14 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
                             w.bv = spf(L, SP_WBV, slot);
                         }
+#ifdef HRT_SP_SEG
+                        asm volatile("" : "+v"(ray.o.x), "+v"(w.t_entry), "+v"(h.t));
+#endif
+                        SEG(0);  // T: record loaded
                         if (act) {
                             walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
                         }
+                        SEG(1);  // T: walk
                         if (act) {
                             const uint32_t pm_in = pm_before;
                             if (pm != pm_in) sp_store_hit(L, slot, h, pm);  // a mesh was finished: the best hit may have changed
@@ -357,6 +366,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         }
                         sp_push(qTo, cTo, act && !walked, slot);  // unfinished: joins the next cycle's T chunks
                         sp_push_hit(L, C, parity ^ 1u, act && walked, kind, slot);
+                        SEG(2);  // T: stores + appends
+#ifdef HRT_SP_SEG
+                        if (seg_on) { seg[7] += 1; seg[6] += (unsigned long long)__popcll(__ballot(act)); seg[5] += (unsigned long long)__popcll(__ballot(act && walked)); }
+#endif
                     } else {
                         // ---------------- S (shade + scatter, then next prims) and G (camera ray, then prims)
                         const bool is_gen = c >= e0;
@@ -369,7 +382,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         const bool act = e < fill;
                         uint32_t slot = 0, kind = 0;
                         bool trace = false, freed = false;  // trace: the path has a new ray to intersect
-                        SEG_START(!is_gen && c >= e1 && c < e2);  // square-hit chunks
+                        SEG_START(HRT_SP_SEG_KIND == 1 && !is_gen && c >= e1 && c < e2);  // square-hit chunks
                         Ray ray;
                         ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
                         if (act && is_gen) {

@@ -106,56 +106,15 @@ RefTreeAnalysis analyse_reference_tree(const float *positions, uint32_t nv, cons
         if (A.dropped[t]) { out.irregular[t] = 1; ++out.n_dropped; }
     }
     // The reference leaves that hold each live irregular triangle.  One that no leaf holds is never hit: no entry.
-    std::vector<hrt_tri_exception> pairs;
     for (size_t l = 0; l < A.leaf_box.size(); ++l)
         for (uint32_t t : A.leaf_tris[l])
             if (out.irregular[t] && !dead[t]) {
                 hrt_tri_exception e;
                 e.triangle = t;
-                e.skip = 0;
                 for (int a = 0; a < 3; ++a) { e.box_min[a] = A.leaf_box[l].lo[a]; e.box_max[a] = A.leaf_box[l].hi[a]; }
-                pairs.push_back(e);
+                out.exceptions.push_back(e);
             }
-    out.n_pairs = (uint32_t)pairs.size();
-    // Bounding hierarchy over the pairs, emitted depth-first with skip links (median split of the box centres on the
-    // widest axis).  Inner boxes are padded: they only cull, the leaf boxes decide.
-    struct Emit {
-        std::vector<hrt_tri_exception> &src, &dst;
-        void run(size_t lo, size_t hi) {
-            if (hi - lo == 1) { dst.push_back(src[lo]); dst.back().skip = (uint32_t)dst.size(); return; }
-            float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-            float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (size_t i = lo; i < hi; ++i)
-                for (int a = 0; a < 3; ++a) {
-                    bmin[a] = std::min(bmin[a], src[i].box_min[a]); bmax[a] = std::max(bmax[a], src[i].box_max[a]);
-                    const float c = 0.5f * (src[i].box_min[a] + src[i].box_max[a]);
-                    cmin[a] = std::min(cmin[a], c); cmax[a] = std::max(cmax[a], c);
-                }
-            int axis = 0;
-            for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-            const size_t mid = lo + (hi - lo) / 2;
-            std::nth_element(src.begin() + lo, src.begin() + mid, src.begin() + hi, [axis](const hrt_tri_exception &x, const hrt_tri_exception &y) {
-                const float cx = x.box_min[axis] + x.box_max[axis], cy = y.box_min[axis] + y.box_max[axis];
-                return cx < cy || (cx == cy && x.triangle < y.triangle);
-            });
-            const size_t self = dst.size();
-            hrt_tri_exception n;
-            n.triangle = HRT_EXC_INNER;
-            n.skip = 0;
-            for (int a = 0; a < 3; ++a) {
-                const float pad = 1e-4f * std::max(1.f, std::max(std::fabs(bmin[a]), std::fabs(bmax[a])));
-                n.box_min[a] = bmin[a] - pad; n.box_max[a] = bmax[a] + pad;
-            }
-            dst.push_back(n);
-            run(lo, mid);
-            run(mid, hi);
-            dst[self].skip = (uint32_t)dst.size();
-        }
-    };
-    if (!pairs.empty()) {
-        Emit em{pairs, out.exceptions};
-        em.run(0, pairs.size());
-    }
+    out.n_pairs = (uint32_t)out.exceptions.size();
     return out;
 }
 

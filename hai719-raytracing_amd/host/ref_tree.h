@@ -30,8 +30,7 @@ namespace hrt_host {
 
 struct RefTreeAnalysis {
     std::vector<uint8_t> irregular;             // per triangle: 1 = keep out of the SAH tree
-    std::vector<hrt_tri_exception> exceptions;  // (triangle, reference leaf box) pairs of the irregular triangles under a
-                                                // bounding hierarchy threaded in depth-first order (include/hrt.h)
+    std::vector<hrt_tri_exception> exceptions;  // (triangle, reference leaf box) pairs of the live irregular triangles (include/hrt.h)
     uint32_t n_dropped = 0, n_slivers = 0, n_dead = 0, n_pairs = 0;  // statistics (n_pairs: leaf entries of `exceptions`)
     uint32_t ref_leaves = 0, ref_depth = 0;
 };

@@ -114,15 +114,10 @@ typedef struct hrt_kdunit {
  * near-degenerate slivers, whose barycentric test (Triangle.h:62-75) accepts phantom points far outside the triangle.
  * Those triangles are kept OUT of the flattened tree (not listed in leaf_tris) and tested exactly when the reference
  * would: when AABB::intersects (AABB.h:48-65) passes for the box of one of the reference leaves that hold them.
- * The list is a bounding hierarchy threaded in depth-first order so that it can be walked without a stack:
- *   leaf entry   triangle = triangle id, box = one reference leaf box that holds it; next entry = this + 1
- *   inner entry  triangle = HRT_EXC_INNER, box = bounds (padded) of the entries [this + 1, skip): a ray that
- *                certainly misses it continues at `skip`, any other ray at this + 1.
- * A plain list (leaf entries only) is valid. */
-#define HRT_EXC_INNER 0xFFFFFFFFu
+ * One entry per (triangle, reference leaf box) pair, in any order; hrt_scene_create groups them by box and builds a
+ * small bounding hierarchy over the distinct boxes. */
 typedef struct hrt_tri_exception {
-    uint32_t triangle;           /* triangle id of the mesh, or HRT_EXC_INNER    */
-    uint32_t skip;               /* inner: index of the first entry behind this subtree; leaf: unused */
+    uint32_t triangle;           /* triangle id of the mesh */
     float box_min[3], box_max[3];
 } hrt_tri_exception;
 

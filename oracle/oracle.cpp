@@ -359,7 +359,6 @@ TriHit rope_tree_intersect(const OMesh &m, const Ray &ray, Counters *cnt) {
     const hrt_mesh &s = *m.src;
     for (uint32_t k = 0; k < s.n_exceptions; ++k) {  // irregular triangles: through their reference leaf boxes (include/hrt.h)
         const hrt_tri_exception &e = s.exceptions[k];
-        if (e.triangle == HRT_EXC_INNER) continue;  // a bounding entry of the threaded list: culls only
         if (!aabb_intersects(e.box_min, e.box_max, ray)) continue;
         TriHit h = leaf_triangle(m, e.triangle, ray, cnt);
         if (h.t < best.t) { best = h; best.tIndex = e.triangle; }

@@ -146,15 +146,14 @@ def test_irregular_triangles_are_found_and_kept_out_of_the_tree(hrt, oracle):
     assert (st["dead"], st["slivers"], st["dropped"], st["entries"]) == (64, 0, 0, 0)
     host = hrt.HostScene().setup("mesh_in_box", 16 / 9, 1); desc = host.flatten()
     st = host.irregular_stats(0)
-    assert (st["dead"], st["slivers"], st["dropped"], st["pairs"]) == (0, 2, 0, 2) and st["entries"] == 3
+    assert (st["dead"], st["slivers"], st["dropped"], st["pairs"]) == (0, 2, 0, 2) and st["entries"] == 2
     d = C.cast(desc, C.POINTER(SceneDesc)).contents
     m = C.cast(d.meshes, C.POINTER(MeshDesc))[0]
     leaf = np.ctypeslib.as_array(C.cast(m.leaf_tris, C.POINTER(C.c_uint32)), shape=(m.n_leaf_tris,))
-    exc = np.ctypeslib.as_array(C.cast(m.exceptions, C.POINTER(C.c_uint32)), shape=(m.n_exceptions, 8))
-    tri = exc[exc[:, 0] != 0xFFFFFFFF][:, 0]
+    exc = np.ctypeslib.as_array(C.cast(m.exceptions, C.POINTER(C.c_uint32)), shape=(m.n_exceptions, 7))  # {triangle, box min, box max}
+    tri = exc[:, 0]
     assert len(tri) == 2 and not np.isin(tri, leaf).any()           # irregular triangles are not in any leaf
     assert len(np.unique(leaf)) == m.n_triangles - 2                # everything else is
-    assert exc[0, 0] == 0xFFFFFFFF and exc[0, 1] == 3               # one bounding entry over the two pairs
     host = hrt.HostScene().setup("raccoon", 16 / 9, 1); host.flatten()
     assert host.irregular_stats(1)["dropped"] > 0 and host.irregular_stats(1)["ref_depth"] == 100
 

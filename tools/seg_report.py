@@ -10,8 +10,16 @@ dev.render(cam, w, h, 2, 1)
 _, st = dev.render(cam, w, h, spp, 1)
 out = (C.c_uint64 * 16)()
 lib = hrt.device_lib(); lib.hrt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]; lib.hrt_debug_read_stamps(dev._h, out)
-names = ["record load", "shade (mat rows, texel, nmap)", "scatter", "write-back / sample store", "spheres + squares", "mesh gates", "stores + appends"]
-tot = sum(out[:7]); n = max(1, out[7])
-print(f"{name} {w}x{h}@{spp}: kernel {st.kernel_ms:.1f} ms, {n} square-hit chunks, {tot / n:.0f} clocks per chunk")
-for k, nm in enumerate(names):
-    print(f"  {nm:32s} {out[k] / n:8.0f} clocks  {100.0 * out[k] / max(1, tot):5.1f} %")
+n = max(1, out[7])
+if os.environ.get("HRT_SEG_KIND") == "2":  # T chunks
+    tot = sum(out[:3])
+    print(f"{name} {w}x{h}@{spp}: kernel {st.kernel_ms:.1f} ms, {n} T chunks, {tot / n:.0f} clocks per chunk, {out[6] / n:.1f} lanes active, "
+          f"{out[5] / max(1, out[6]) * 100:.1f} % of the visits finish their walk")
+    for k, nm in enumerate(["record load", "walk (6 trips)", "stores + appends"]):
+        print(f"  {nm:32s} {out[k] / n:8.0f} clocks  {100.0 * out[k] / max(1, tot):5.1f} %")
+else:
+    names = ["record load", "shade (mat rows, texel, nmap)", "scatter", "write-back / sample store", "spheres + squares", "mesh gates", "stores + appends"]
+    tot = sum(out[:7])
+    print(f"{name} {w}x{h}@{spp}: kernel {st.kernel_ms:.1f} ms, {n} square-hit chunks, {tot / n:.0f} clocks per chunk")
+    for k, nm in enumerate(names):
+        print(f"  {nm:32s} {out[k] / n:8.0f} clocks  {100.0 * out[k] / max(1, tot):5.1f} %")
