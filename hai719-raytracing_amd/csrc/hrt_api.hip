@@ -192,17 +192,17 @@ void build_quad_filter(const std::vector<float4> &quads, uint32_t nq, std::vecto
 }
 
 // Triangle(c0,c1,c2) + computeBarycentricCoordinates constants (Triangle.h:26-37, 62-70) -> the 5 rows of hrt_device.h.
-void fold_triangle(const H3 c[3], uint32_t id, std::vector<float4> &tris) {
+void fold_triangle(const H3 c[3], uint32_t id, std::vector<float4> &tris, std::vector<float4> &planes) {
     const H3 e1 = h_sub(c[1], c[0]), e2 = h_sub(c[2], c[0]);
     const H3 nn = h_cross(e1, e2);
     const float norm = h_len(nn);
     const H3 n{nn.x / norm, nn.y / norm, nn.z / norm};
     const float d00 = h_dot(e1, e1), d01 = h_dot(e1, e2), d11 = h_dot(e2, e2);
     const float denom = h_msub(d00, d11, d01, d01);
+    planes.push_back(make_float4(n.x, n.y, n.z, h_dot(c[0], n)));
     tris.push_back(make_float4(c[0].x, c[0].y, c[0].z, as_float(id)));
     tris.push_back(make_float4(e1.x, e1.y, e1.z, d00));
     tris.push_back(make_float4(e2.x, e2.y, e2.z, d01));
-    tris.push_back(make_float4(n.x, n.y, n.z, h_dot(c[0], n)));
     tris.push_back(make_float4(d11, denom, 0.f, 0.f));
 }
 
@@ -432,7 +432,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     // ---- meshes: nodelets (refs rebased), leaf-ordered triangle soup, colours
     std::vector<DMesh> meshes;
     std::vector<uint4> units;
-    std::vector<float4> tris, colors, exceptions;
+    std::vector<float4> tris, planes, colors, exceptions;
     std::vector<uint4> vids;
     for (uint32_t mi = 0; mi < D.n_meshes; ++mi) {
         const hrt_mesh &M = D.meshes[mi];
@@ -505,7 +505,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 const float *p = M.positions + 3 * (size_t)M.indices[3 * (size_t)t + j];
                 c[j] = H3{p[0] * HRT_TRIANGLE_SCALING, p[1] * HRT_TRIANGLE_SCALING, p[2] * HRT_TRIANGLE_SCALING};
             }
-            fold_triangle(c, t, tris);
+            fold_triangle(c, t, tris, planes);
         };
         for (uint32_t k = 0; k < M.n_leaf_tris; ++k) {
             const uint32_t t = M.leaf_tris[k];
@@ -648,6 +648,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     UP(qfilter, qfilter, float4)
     UP(units, kd_units, uint4)
     UP(tris, tris, float4)
+    UP(planes, tri_planes, float4)
     UP(colors, colors, float4)
     UP(vids, tri_vids, uint4)
     UP(images, images, DImage)
@@ -1138,7 +1139,9 @@ int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, cons
         if (rc != HRT_OK) return rc;
     } else if (which == HRT_KAT_TRIANGLE) {  // prim: c0, c1, c2 as handed to the Triangle constructor
         const H3 c[3] = {{prim[0], prim[1], prim[2]}, {prim[3], prim[4], prim[5]}, {prim[6], prim[7], prim[8]}};
-        fold_triangle(c, 0u, rows);
+        std::vector<float4> rest;
+        fold_triangle(c, 0u, rest, rows);           // plane first, then the HRT_TRI_ROWS others (hrt_kat_triangle_kernel)
+        rows.insert(rows.end(), rest.begin(), rest.end());
     } else if (which == HRT_KAT_AABB) {
         box.assign(prim, prim + 6);
     } else if (which == HRT_KAT_SPHERE) {    // prim: centre, radius, motion

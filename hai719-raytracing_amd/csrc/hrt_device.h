@@ -19,7 +19,8 @@
 //   exceptions    irregular triangles (include/hrt.h hrt_tri_exception) by distinct reference leaf box: leaf entry {box lo, first soup
 //                 slot} {box hi, count} (the triangles' rows sit contiguously behind the mesh's leaf-ordered soup), bounding entry
 //                 {lo, HRT_EXC_INNER} {hi, skip}, threaded depth-first
-//   triangles     leaf-ordered soup, 5 float4 rows: {c0, id} {e1, d00} {e2, d01} {n, D} {d11, denom, -, -}
+//   triangles     leaf-ordered soup in two arrays by slot: planes {n, D} (16 B: the planes of a leaf's triangles share a cache line) and
+//                 rows {c0, id} {e1, d00} {e2, d01} {d11, denom, -, -} (one 64-byte line, read only when the plane is hit in front)
 //                 (Triangle.h:32-37, 62-75 constants folded on the host in the reference's arithmetic)
 //   colours       float4 per face / per vertex (+ uint4 vertex ids per triangle)
 //   texels        RGBA8 packed in a u32, one table entry {offset, w, h} per image
@@ -33,7 +34,7 @@
 #define HRT_QUAD_ROWS 7
 #define HRT_SPHERE_ROWS 2
 #define HRT_MAT_ROWS 8
-#define HRT_TRI_ROWS 5
+#define HRT_TRI_ROWS 4   // {c0, id} {e1, d00} {e2, d01} {d11, denom}: one 64-byte line per triangle; the plane {n, D} lives in DScene::tri_planes
 #define HRT_EXC_INNER 0xFFFFFFFFu  // first word of a bounding entry of a mesh's exception list (DScene::exceptions)
 #define HRT_QUAD_FLAG_GLASS 1u
 #define HRT_QUAD_FLAG_MOVING 2u
@@ -64,7 +65,8 @@ struct DScene {
     const float4 *materials;
     const DMesh *meshes;
     const uint4 *kd_units;
-    const float4 *tris;
+    const float4 *tris;        // HRT_TRI_ROWS rows per soup slot
+    const float4 *tri_planes;  // {n, D} per soup slot
     const float4 *colors;
     const uint4 *tri_vids;
     const DImage *images;

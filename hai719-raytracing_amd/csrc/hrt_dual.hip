@@ -139,7 +139,7 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
         w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
     }
     gu4 g_units = (gu4)cx.S->kd_units;
-    gf4 tris = (gf4)cx.S->tris;
+    const Soup sp = soup_of(cx.S);
     const uint32_t tri_base = M->tri_base;
     uint32_t ref = w.ref, k = w.kk & 0xFFFFu, count = w.kk >> 16;
     float t_entry = w.t_entry;
@@ -165,8 +165,8 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
             const uint32_t first = tri_base + l0.w, cnt = l1.w;
             if (k == 0xFFFFu) k = 0;
             if (k < cnt) {
-                if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, w.best_t, w.bu, w.bv)) w.best_tri = first + k;
-                ++k;
+                bool found_ = false;
+                k = tri_test_run(sp, first, cnt, k, ray, w.best_t, w.best_tri, w.bu, w.bv, found_);
             }
             if (k >= cnt) {  // leave the cell through its exit face
                 const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;

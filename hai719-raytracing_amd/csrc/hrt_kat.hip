@@ -30,15 +30,15 @@ extern "C" __global__ void hrt_kat_camera_kernel(const DCamera *cam, const float
     o[6] = b.o.x; o[7] = b.o.y; o[8] = b.o.z; o[9] = b.d.x; o[10] = b.d.y; o[11] = b.d.z;
 }
 
-// rows: the 5 folded rows of one triangle.  out n x 8: hit, t, w0, w1, w2, normal (Triangle.h:110-118)
+// rows: the folded rows of one triangle, plane {n, D} first, then the HRT_TRI_ROWS others.  out n x 8: hit, t, w0, w1, w2, normal (Triangle.h:110-118)
 extern "C" __global__ void hrt_kat_triangle_kernel(const float4 *rows, const float *__restrict__ rays, uint32_t n, float *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Ray ray = kat_ray(rays, i);
     float t = HRT_FLT_MAX, u1 = 0.f, u2 = 0.f;
-    const bool hit = tri_test((gf4)rows, ray, t, u1, u2);
+    const float4 r3 = ld((gf4)rows, 0);
+    const bool hit = tri_test_plane((gf4)rows + 1, r3, ray, t, u1, u2);
     float *o = out + 8 * (size_t)i;
-    const float4 r3 = ld((gf4)rows, 3);
     o[0] = hit ? 1.f : 0.f; o[1] = hit ? t : 0.f;
     o[2] = hit ? 1 - u1 - u2 : 0.f; o[3] = hit ? u1 : 0.f; o[4] = hit ? u2 : 0.f;
     o[5] = hit ? r3.x : 0.f; o[6] = hit ? r3.y : 0.f; o[7] = hit ? r3.z : 0.f;

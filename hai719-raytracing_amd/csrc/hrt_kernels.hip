@@ -322,20 +322,24 @@ __device__ __forceinline__ uint4 kd_fetch(gu4 g, const CX &cx, uint32_t i) {
 }
 
 // One triangle of the soup against the ray: Triangle::getIntersection (Triangle.h:77-126) with the constructor's and
-// computeBarycentricCoordinates' constants folded on the host (rows 0 {c0, id} 1 {e1, d00} 2 {e2, d01} 3 {n, D} 4 {d11, denom}),
-// then the leaf's strict `<` against the best so far (KDTree.cpp:44).  True when this triangle became the best.
-__device__ __forceinline__ bool tri_test_r3(gf4 tr, const float4 r3, const Ray &ray, float &best_t, float &bu, float &bv);
-__device__ __forceinline__ bool tri_test(gf4 tr, const Ray &ray, float &best_t, float &bu, float &bv) {
-    return tri_test_r3(tr, ld(tr, 3), ray, best_t, bu, bv);
-}
-// the same with row 3 {n, D} already in registers (a caller that tests a run of triangles requests several ahead)
-__device__ __forceinline__ bool tri_test_r3(gf4 tr, const float4 r3, const Ray &ray, float &best_t, float &bu, float &bv) {
-    const f3 n = mk(r3);
+// computeBarycentricCoordinates' constants folded on the host, then the leaf's strict `<` against the best so far
+// (KDTree.cpp:44).  True when this triangle became the best.  The soup is two arrays indexed by slot:
+//   planes  {n, D}: 16 bytes, so the planes of a leaf's (<= 4) triangles share one cache line -- the plane test rejects most
+//   rows    {c0, id} {e1, d00} {e2, d01} {d11, denom}: one aligned 64-byte line, fetched only by a triangle whose plane is hit in front
+#ifndef HRT_LEAF_BATCH
+#define HRT_LEAF_BATCH 2   // triangles of a leaf tested per trip of a walk, their planes requested together
+#endif
+struct Soup {
+    gf4 planes, rows;
+};
+__device__ __forceinline__ Soup soup_of(cscene S) { return Soup{(gf4)S->tri_planes, (gf4)S->tris}; }
+__device__ __forceinline__ bool tri_test_plane(gf4 tr, const float4 pl, const Ray &ray, float &best_t, float &bu, float &bv) {
+    const f3 n = mk(pl);
     const float dotRN = dot(ray.d, n);
     if (!(dotRN < 0.f)) return false;                     // :80-91 parallel / back-facing (NaN: no hit)
-    const float t = (r3.w - dot(ray.o, n)) / dotRN;       // :95
+    const float t = (pl.w - dot(ray.o, n)) / dotRN;       // :95
     if (t < 0.f || !(t < best_t)) return false;           // :96, then KDTree.cpp:44
-    const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 4);
+    const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 3);
     const f3 v2 = (ray.o + t * ray.d) - mk(r0);
     const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
     const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;    // :72-74
@@ -344,6 +348,21 @@ __device__ __forceinline__ bool tri_test_r3(gf4 tr, const float4 r3, const Ray &
     if (!(u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1)) return false;
     best_t = t; bu = u1; bv = u2;
     return true;
+}
+__device__ __forceinline__ bool tri_test(const Soup &sp, uint32_t slot, const Ray &ray, float &best_t, float &bu, float &bv) {
+    return tri_test_plane(sp.rows + HRT_TRI_ROWS * slot, ld(sp.planes, slot), ray, best_t, bu, bv);
+}
+// Triangles [k, min(k + HRT_LEAF_BATCH, cnt)) of the run that starts at soup slot `first`, in order; returns the new k.
+// Requires k < cnt.
+__device__ __forceinline__ uint32_t tri_test_run(const Soup &sp, uint32_t first, uint32_t cnt, uint32_t k, const Ray &ray, float &best_t,
+                                                 uint32_t &best_tri, float &bu, float &bv, bool &found) {
+    float4 pl[HRT_LEAF_BATCH];
+#pragma unroll
+    for (uint32_t j = 0; j < HRT_LEAF_BATCH; ++j) pl[j] = ld(sp.planes, first + min(k + j, cnt - 1u));  // clamped: stays inside the run
+#pragma unroll
+    for (uint32_t j = 0; j < HRT_LEAF_BATCH; ++j)
+        if (k + j < cnt && tri_test_plane(sp.rows + HRT_TRI_ROWS * (first + k + j), pl[j], ray, best_t, bu, bv)) { best_tri = first + k + j; found = true; }
+    return min(k + (uint32_t)HRT_LEAF_BATCH, cnt);
 }
 
 // The IRREGULAR triangles of a mesh (include/hrt.h hrt_tri_exception; host/ref_tree.h): triangles the reference's builder
@@ -355,7 +374,7 @@ __device__ __forceinline__ bool mesh_exceptions_walk(cscene S, EP ex_all, MP M, 
     const uint32_t n = M->n_exc;
     bool found = false;
     const EP ex = ex_all + 2u * M->exc_base;
-    gf4 tris = (gf4)S->tris;
+    const Soup sp = soup_of(S);
     // entries {box lo, first soup slot | HRT_EXC_INNER} {box hi, count | skip}: the distinct reference leaf boxes under a
     // bounding hierarchy threaded depth-first (hrt_api.hip scene_create_impl)
     for (uint32_t i = 0; i < n;) {
@@ -367,14 +386,8 @@ __device__ __forceinline__ bool mesh_exceptions_walk(cscene S, EP ex_all, MP M, 
         if (first == HRT_EXC_INNER) {  // bounds of a subtree: only culls (never in the proof builds)
             if (!EXACT && gate_filter(b, ray, inv) < 0) i = cnt;
         } else if (mesh_gate_box<EXACT>(b, ray, inv)) {  // the ray passes this reference leaf: its irregular triangles are tested
-            for (uint32_t k = 0; k < cnt; k += 4u) {  // four plane rows in flight: a run can be long (a leaf the reference's builder gave up on)
-                float4 r3[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) r3[j] = ld(tris + HRT_TRI_ROWS * (first + min(k + j, cnt - 1u)), 3);
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j)
-                    if (k + j < cnt && tri_test_r3(tris + HRT_TRI_ROWS * (first + k + j), r3[j], ray, best_t, bu, bv)) { best_tri = first + k + j; found = true; }
-            }
+            for (uint32_t k = 0; k < cnt;)  // a run can be long (a leaf the reference's builder gave up on): planes are requested in batches
+                k = tri_test_run(sp, first, cnt, k, ray, best_t, best_tri, bu, bv, found);
         }
     }
     return found;
@@ -394,12 +407,11 @@ __device__ __forceinline__ bool mesh_exceptions(const CX &cx, MP M, const Ray &r
 // walk at frame scale: the walk only chooses WHICH triangles are tested, so both must select the same closest hit.
 template <class CX>
 __device__ __forceinline__ bool mesh_brute(const CX &cx, cmesh M, const Ray &ray, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
-    gf4 tris = (gf4)cx.S->tris;
+    const Soup sp = soup_of(cx.S);
     const uint32_t first = M->tri_base, cnt = M->n_soup;
     best_t = HRT_FLT_MAX;
     bool found = mesh_exceptions<true>(cx, M, ray, mk(0.f, 0.f, 0.f), best_t, best_tri, bu, bv);
-    for (uint32_t k = 0; k < cnt; ++k)
-        if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, best_t, bu, bv)) { best_tri = first + k; found = true; }
+    for (uint32_t k = 0; k < cnt;) k = tri_test_run(sp, first, cnt, k, ray, best_t, best_tri, bu, bv, found);
     return found;
 }
 
@@ -424,11 +436,11 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
     bool found = mesh_exceptions<CX::exact>(cx, M, ray, inv, best_t, best_tri, bu, bv);
     if (!(t_entry <= t_scene_exit)) return found;
     gu4 g_units = (gu4)cx.S->kd_units;
-    gf4 tris = (gf4)cx.S->tris;
+    const Soup sp = soup_of(cx.S);
     const uint32_t tri_base = M->tri_base;
     // One flat loop, one small unit of work per lane per trip (descend <= 2 levels, then enter the leaf /
-    // test ONE triangle / leave through a rope): a trip costs the same for all lanes and the trip count is
-    // the largest number of units any lane needs.
+    // test up to HRT_LEAF_BATCH of its triangles / leave through a rope): a trip costs about the same for all
+    // lanes and the trip count is the largest number of units any lane needs.
     uint32_t ref = M->root;
     uint32_t k = 0, cnt = ~0u, first = 0;  // triangle cursor of the current leaf; cnt == ~0: leaf not entered yet
     f3 p = ray.o + t_entry * ray.d;
@@ -455,10 +467,7 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
 #ifdef HRT_ABL_NO_TRI  // ablation only
             k = cnt;
 #endif
-            if (k < cnt) {
-                if (tri_test(tris + HRT_TRI_ROWS * (first + k), ray, best_t, bu, bv)) { best_tri = first + k; found = true; }
-                ++k;
-            }
+            if (k < cnt) k = tri_test_run(sp, first, cnt, k, ray, best_t, best_tri, bu, bv, found);
             if (k >= cnt) {  // leave the cell through its exit face
                 const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
                 const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
@@ -879,8 +888,7 @@ __device__ __forceinline__ Surface shade(const CX &cx, const Ray &ray, const Hit
         const typename CX::tabmesh M = cx.tmesh + h.index;  // per-lane mesh record
         mat_id = M->material;
         const float4 m0 = ld(mats, HRT_MAT_ROWS * mat_id);
-        gf4 tr = (gf4)S->tris + HRT_TRI_ROWS * h.tri;
-        const float4 r0 = ld(tr, 0), r3 = ld(tr, 3);
+        const float4 r0 = ld((gf4)S->tris, HRT_TRI_ROWS * h.tri), r3 = ld((gf4)S->tri_planes, h.tri);
         sf.n = mk(r3);  // Triangle.h:32-37 flat normal, folded on the host
         sf.albedo = mk(m0);
         const uint32_t tid = __float_as_uint(r0.w);
