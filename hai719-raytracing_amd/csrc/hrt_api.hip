@@ -147,43 +147,53 @@ void fold_quad(const hrt_quad &q, const hrt_material &m, std::vector<float4> &qu
 }
 
 // The rows of the squares' no-division filter (hrt_device.h DScene::qfilter; hrt_kernels.hip quad_filter), from the folded
-// rows: sections for axis-aligned static squares by normal axis, then all others.  A square is "axis-aligned" only when
-// that is EXACTLY so in the folded fp32 values -- normal (+-1 on one axis K, zero elsewhere), R along one of the other two
-// axes and U along the remaining one: then every product with a zero component is an exact zero in the reference's
-// arithmetic and its plane distance reduces exactly to (p0_K - o_K) / d_K.
+// rows: sections for static squares lying (nearly) in an axis plane, by normal axis, then all others.  The constants of
+// the axis form and the error analysis behind them are stated at quad_filter_axis.
 void build_quad_filter(const std::vector<float4> &quads, uint32_t nq, std::vector<float4> &qf, uint32_t count[4]) {
     std::vector<float4> sec[4];
     for (int k = 0; k < 4; ++k) count[k] = 0;
     for (uint32_t i = 0; i < nq; ++i) {
         const float4 *q = &quads[(size_t)HRT_QUAD_ROWS * i];
-        const float p0[3] = {q[0].x, q[0].y, q[0].z}, n[3] = {q[1].x, q[1].y, q[1].z}, R[3] = {q[2].x, q[2].y, q[2].z}, U[3] = {q[3].x, q[3].y, q[3].z};
+        const double p0[3] = {q[0].x, q[0].y, q[0].z}, n[3] = {q[1].x, q[1].y, q[1].z}, R[3] = {q[2].x, q[2].y, q[2].z}, U[3] = {q[3].x, q[3].y, q[3].z};
+        const double lenR = q[2].w, lenU = q[3].w;
         uint32_t flags;
         std::memcpy(&flags, &q[1].w, 4);
-        int K = -1;
-        if (!(flags & HRT_QUAD_FLAG_MOVING))
-            for (int k = 0; k < 3; ++k) {
-                const int a = (k + 1) % 3, b = (k + 2) % 3;
-                const bool normal_ok = std::fabs(n[k]) == 1.f && n[a] == 0.f && n[b] == 0.f;
-                const bool ru = R[k] == 0.f && U[k] == 0.f && R[b] == 0.f && U[a] == 0.f && R[a] != 0.f && U[b] != 0.f;   // R along a, U along b
-                const bool ur = R[k] == 0.f && U[k] == 0.f && R[a] == 0.f && U[b] == 0.f && R[b] != 0.f && U[a] != 0.f;   // or the other way round
-                if (normal_ok && (ru || ur)) K = k;
-            }
+        int K = -1, ra = -1;   // normal axis; axis R runs along
+        double eps_n = 0.0, eps_e = 0.0;
+        if (!(flags & HRT_QUAD_FLAG_MOVING) && lenR > 0.0 && lenU > 0.0) {
+            int k = 0;
+            for (int c = 1; c < 3; ++c) if (std::fabs(n[c]) > std::fabs(n[k])) k = c;
+            const int a = (k + 1) % 3, b = (k + 2) % 3;
+            eps_n = std::fabs(n[a]) + std::fabs(n[b]) + std::fabs(1.0 - std::fabs(n[k]));
+            const double dev_ab = (std::fabs(R[k]) + std::fabs(R[b])) / lenR + (std::fabs(U[k]) + std::fabs(U[a])) / lenU;  // R along a, U along b
+            const double dev_ba = (std::fabs(R[k]) + std::fabs(R[a])) / lenR + (std::fabs(U[k]) + std::fabs(U[b])) / lenU;  // or the other way round
+            eps_e = std::min(dev_ab, dev_ba);
+            if (eps_n <= 1e-4 && eps_e <= 1e-4 && std::isfinite(eps_n) && std::isfinite(eps_e)) { K = k; ra = dev_ab <= dev_ba ? a : b; }
+        }
         if (K >= 0) {
             const int a = (K + 1) % 3, b = (K + 2) % 3;
-            const double ea = (double)R[a] + (double)U[a], eb = (double)R[b] + (double)U[b];  // one of each pair is zero
-            // centres and half extents rounded outwards by an ulp: the filter must never be tighter than the exact test
-            const float ca = (float)((double)p0[a] + 0.5 * ea), cb = (float)((double)p0[b] + 0.5 * eb);
-            const float ha = std::nextafter((float)(0.5 * std::fabs(ea)) + std::fabs(ca) * 1.2e-7f, INFINITY);
-            const float hb = std::nextafter((float)(0.5 * std::fabs(eb)) + std::fabs(cb) * 1.2e-7f, INFINITY);
-            const uint32_t bits = ((flags & HRT_QUAD_FLAG_GLASS) ? 1u : 0u) | (n[K] < 0.f ? 2u : 0u) | (i << 8);
-            sec[K].push_back(make_float4(p0[K], ca, cb, ha));
-            sec[K].push_back(make_float4(hb, as_float(bits), 0.f, 0.f));
+            (void)ra;
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int c = 0; c < 4; ++c)      // the four corners p0, p0 + R, p0 + U, p0 + R + U
+                for (int x = 0; x < 3; ++x) {
+                    const double v = p0[x] + ((c & 1) ? R[x] : 0.0) + ((c & 2) ? U[x] : 0.0);
+                    lo[x] = std::min(lo[x], v); hi[x] = std::max(hi[x], v);
+                }
+            const double widen = (2.0 * eps_e + 2e-6) * (lenR + lenU);  // proj = qq.R / |R| against qq_a, and its own rounding
+            auto centre = [&](int x) { return (float)(0.5 * (lo[x] + hi[x])); };
+            auto half = [&](int x) { return std::nextafter((float)(0.5 * (hi[x] - lo[x]) + widen + 2.4e-7 * (std::fabs(lo[x]) + std::fabs(hi[x]))), INFINITY); };
+            const float sgn = n[K] < 0.0 ? -1.f : 1.f;
+            const float par = (float)(8.0 * (eps_n + 4e-7));
+            const float cq = (float)(2.5e6 * (eps_n + 3e-7));
+            const uint32_t bits = ((flags & HRT_QUAD_FLAG_GLASS) ? 1u : 0u) | (sgn < 0.f ? 2u : 0u) | (i << 8);
+            sec[K].push_back(make_float4(sgn * q[0].w, centre(a), centre(b), half(a)));
+            sec[K].push_back(make_float4(half(b), as_float(bits), par, cq));
             ++count[K];
         } else {
-            sec[3].push_back(make_float4(p0[0], p0[1], p0[2], q[0].w));
-            sec[3].push_back(make_float4(n[1], n[2], n[0], as_float(flags | (i << 8))));
-            sec[3].push_back(make_float4(R[0], U[0], R[1], U[1]));
-            sec[3].push_back(make_float4(R[2], U[2], q[2].w, q[3].w));
+            sec[3].push_back(make_float4(q[0].x, q[0].y, q[0].z, q[0].w));
+            sec[3].push_back(make_float4(q[1].y, q[1].z, q[1].x, as_float(flags | (i << 8))));
+            sec[3].push_back(make_float4(q[2].x, q[3].x, q[2].y, q[3].y));
+            sec[3].push_back(make_float4(q[2].z, q[3].z, q[2].w, q[3].w));
             ++count[3];
         }
     }

@@ -10,7 +10,7 @@
 //     quad    5 rows: {p0.xyz, D0} {n.xyz, flags} {R.xyz, |R|} {U.xyz, |U|} {motion.xyz, material}
 //             + 2 rows used only when shading: {T.xyz,0} {B.xyz,0}
 //   quad filter   DScene::qfilter, wave-uniform rows of the no-division filter (hrt_kernels.hip quad_filter):
-//               axis-aligned static squares, by normal axis K: {p0_K, centre_I, centre_J, half_I} {half_J, bits, -, -}
+//               static squares (nearly) in an axis plane, by normal axis K: {sgn D, centre_I, centre_J, half_I} {half_J, bits, par, cq}
 //               all others, laid out as the SGPR pairs the packed-fp32 instructions take:
 //               {p0.xyz, D0} {n.y, n.z, n.x, flags | index << 8} {R.x, U.x, R.y, U.y} {R.z, U.z, |R|, |U|}
 //   materials     8 float4 rows per material, read per lane at the closest hit (rows 6, 7: geometry of its texture / normal map)
@@ -76,7 +76,7 @@ struct DScene {
                                // point into): the streaming kernel stages it in LDS for per-lane row fetches (hrt_kernels.hip CtxT)
     uint32_t tab_quads, tab_mats, tab_spheres, tab_meshes, tab_exc, tab_rows;  // row offsets of the tables, rows in all
     uint32_t exc_in_tabs;      // 1: the meshes' exception lists are short (<= 512 rows) and sit in `tabs` at tab_exc; 0: in `exceptions`
-    const float4 *qfilter;     // rows of the squares' no-division filter: axis-aligned squares by normal axis x, y, z (2 rows each), then the rest (4 rows each)
+    const float4 *qfilter;     // rows of the squares' no-division filter: squares in an axis plane by normal axis x, y, z (2 rows each), then the rest (4 rows each)
     uint32_t qf_n[4];          // squares per section
     const float4 *exceptions;  // 2 rows per entry (see above)
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;

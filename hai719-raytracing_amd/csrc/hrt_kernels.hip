@@ -503,28 +503,36 @@ __device__ __forceinline__ f3 ray_inv(const Ray &ray) {
 template <int A>
 __device__ __forceinline__ float cget(f3 v) { return A == 0 ? v.x : (A == 1 ? v.y : v.z); }
 
-// FILTER, axis-aligned squares (most walls of the reference's scenes).  The host recognises a static square whose folded
-// normal is exactly +-e_K and whose edges R, U run along the other two axes (hrt_api.hip classify_aa) and stores it as
-//   r0 {p0_K, centre_I, centre_J, half_I}   r1 {half_J, bits, -, -}      bits: 1 glass, 2 normal points to -K, square index << 8
-// For such a square the reference's t = (D - o.n) / (d.n) IS (p0_K - o_K) / d_K (zeros multiply and add exactly, the sign
-// cancels), and its inside test reads "p_I, p_J within the rectangle" up to rounding -- so the filter needs one
-// subtraction, one multiplication by the ray's reciprocal (computed once per ray), two fma and a handful of compares:
-// 19 VALU instead of the 40 of the general form below, with the same margins (e bounds |p' - p|, see there).
+// FILTER, squares that lie (nearly) in an axis plane -- every wall of the reference's scenes: setQuad builds them axis-
+// aligned and the set-up code's rotate_x / rotate_y by multiples of 90 degrees leave residues of a few 1e-8 in the other
+// components (cos(pi/2) in fp32).  The host recognises a static square whose folded normal is within eps_n of +-e_K and
+// whose edges run within the same tolerance along the other two axes (hrt_api.hip build_quad_filter) and stores
+//   r0 {sgn * D, centre_I, centre_J, half_I}   r1 {half_J, bits, par, cq}     bits: 1 glass, 2 normal along -K, square index << 8
+// The reference's t = (D - o.n) / (d.n) then differs from ta = (sgn * D - o_K) / d_K by at most
+//   |t - ta| <= 1.15 (eps_n + 3e-7) (ext + |ta|) / |d_K|        (numerator and denominator each off by <= eps_n (ext | 1);
+//                                                                 3e-7: the reference's own rounding; valid for |d_K| >= 8 eps_n)
+// and a hit has |ta| <= 3 ext (ext = scene + camera extent = err_abs / 2e-6), so with cq = 2.5e6 (eps_n + 3e-7) the
+// margin  E = cq |1/d_K| err_abs + 5e-6 |ta| + err_abs  bounds |t - ta| and the distance between the filter's hit point
+// and the reference's.  The rectangle bounds along I, J are those of the four corners, widened on the host by the same
+// kind of term.  Rays with |d_K| < par (= 8 (eps_n + 4e-7)) are too parallel to judge: they go to the exact arithmetic.
+// 21 VALU per square instead of the 40 of the general form below; the reciprocal is taken once per ray and axis.
 template <class M, int K, class CX>
-__device__ __forceinline__ void quad_filter_aa(const CX &cx, const Ray &ray, f3 inv, cf4 rows, uint32_t n, float tsure_up, M &cand) {
+__device__ __forceinline__ void quad_filter_axis(const CX &cx, const Ray &ray, f3 inv, cf4 rows, uint32_t n, float tsure_up, M &cand) {
     constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
     const float ok = cget<K>(ray.o), dk = cget<K>(ray.d), ik = cget<K>(inv);
     const float oi = cget<I>(ray.o), di = cget<I>(ray.d), oj = cget<J>(ray.o), dj = cget<J>(ray.d);
+    const float iek = fabsf(ik) * cx.err_abs;
     auto test = [&](const float4 &r0, const float4 &r1) {
         const uint32_t bits = __float_as_uint(r1.y);
-        const float ta = (r0.x - ok) * ik;                               // within 3 ulp of the reference's t
+        const float ta = (r0.x - ok) * ik;
         const float xi = __builtin_fmaf(ta, di, oi) - r0.y, xj = __builtin_fmaf(ta, dj, oj) - r0.z;
-        const float e = __builtin_fmaf(fabsf(ta), 4e-6f, cx.err_abs);    // bound on |p' - p|, generous
-        const float dn = __uint_as_float(__float_as_uint(dk) ^ ((bits & 2u) << 30));  // d . n = +-d_K exactly
+        const float E = __builtin_fmaf(r1.w, iek, __builtin_fmaf(fabsf(ta), 5e-6f, cx.err_abs));
+        const float dn = __uint_as_float(__float_as_uint(dk) ^ ((bits & 2u) << 30));  // sgn * d_K ~ d . n
         const bool glass = (bits & 1u) != 0u;
-        const bool front = (dn < 0.f) | (glass & (dn > 0.f));  // `|`, `&`: lane masks combined, no short-circuit branches
-        const bool loose = front & (ta >= 9e-6f) & (ta <= tsure_up) & (fabsf(xi) <= r0.w + e) & (fabsf(xj) <= r1.x + e);
-        if (loose) cand |= (M)1 << (bits >> 8);
+        const bool front = glass | (dn < r1.z);
+        const bool unsure = fabsf(dk) < r1.z;
+        const bool loose = front & (ta + E >= 9e-6f) & (ta - E <= tsure_up) & (fabsf(xi) <= r0.w + E) & (fabsf(xj) <= r1.x + E);
+        if (loose | unsure) cand |= (M)1 << (bits >> 8);
     };
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;  // two row sets in ping-pong (see quad_filter)
     if (n > 0u) { a0 = ld(rows, 0); a1 = ld(rows, 1); }
@@ -541,8 +549,8 @@ __device__ __forceinline__ void quad_filter_aa(const CX &cx, const Ray &ray, f3 
 
 // The no-division FILTER over the squares (wave-uniform loops, scalar rows): bit i of the result = square i can possibly
 // be the closest accepted hit (see prims_hit).  M = uint32_t for up to 32 squares (the per-lane mask costs half the VALU
-// work of a 64-bit one), uint64_t for up to 64.  The filter rows live in DScene::qfilter in four sections: axis-aligned
-// squares by normal axis (x, y, z; 2 rows each, quad_filter_aa), then all others (4 rows each, below).
+// work of a 64-bit one), uint64_t for up to 64.  The filter rows live in DScene::qfilter in four sections: squares in an
+// axis plane by normal axis (x, y, z; 2 rows each, quad_filter_axis), then all others (4 rows each, below).
 template <class M, class CX>
 __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsure) {
     M cand = 0;
@@ -552,9 +560,9 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsu
     const uint32_t n0 = S->qf_n[0], n1 = S->qf_n[1], n2 = S->qf_n[2], n3 = S->qf_n[3];
     if (n0 + n1 + n2 != 0u) {
         const f3 inv = ray_inv<false>(ray);
-        quad_filter_aa<M, 0>(cx, ray, inv, qf, n0, tsure_up, cand);
-        quad_filter_aa<M, 1>(cx, ray, inv, qf + 2u * n0, n1, tsure_up, cand);
-        quad_filter_aa<M, 2>(cx, ray, inv, qf + 2u * (n0 + n1), n2, tsure_up, cand);
+        quad_filter_axis<M, 0>(cx, ray, inv, qf, n0, tsure_up, cand);
+        quad_filter_axis<M, 1>(cx, ray, inv, qf + 2u * n0, n1, tsure_up, cand);
+        quad_filter_axis<M, 2>(cx, ray, inv, qf + 2u * (n0 + n1), n2, tsure_up, cand);
     }
     // General squares.  Two row sets in ping-pong: while quad i is evaluated from one set, the rows of quad i + 1 are
     // already in flight into the other, and quad i + 2 is requested into the first as soon as quad i is done -- the scalar
