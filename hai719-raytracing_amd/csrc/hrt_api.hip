@@ -458,6 +458,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
             dm.aabb_lo[a] = M.aabb_min[a]; dm.aabb_hi[a] = M.aabb_max[a];
             dm.kd_lo[a] = M.kd_min[a]; dm.kd_hi[a] = M.kd_max[a];
         }
+        units.resize((units.size() + 3u) & ~(size_t)3u, make_uint4(0, 0, 0, 0));  // every mesh's nodelets start on a 64-byte line (the host aligns clusters and leaves)
         const uint32_t unit_base = (uint32_t)units.size();
         const uint32_t tri_base = (uint32_t)(tris.size() / HRT_TRI_ROWS);
         auto rebase = [&](uint32_t ref, bool &ok) -> uint32_t {

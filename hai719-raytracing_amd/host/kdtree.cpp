@@ -292,19 +292,33 @@ FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t
     b.assign_ropes(root_node, nil);
     const auto t_roped = std::chrono::steady_clock::now();
 
-    // Breadth-first numbering in 16-byte units: inner = 1 unit, leaf = 4 units.
+    // Numbering in 16-byte units (inner = 1 unit, leaf = 4 units), made for 64-byte cache lines: the walk's loads are
+    // dependent (node -> child -> ... -> leaf header -> rope), and a hop that stays inside the line the previous hop just
+    // brought in costs an L1 hit instead of an L2 / Infinity-Cache round trip.
+    //   * clusters {node, its inner children} are kept inside one 64-byte line (padding where needed): going from a cluster
+    //     root to either child is a same-line hop, so only every second level of a descent pays a far access;
+    //   * leaves start on 64-byte boundaries: bounds, triangle range and all six ropes come with one line;
+    //   * clusters are emitted breadth-first, so a prefix of the array is still the top of the tree (what the kernels stage
+    //     into LDS).
     std::vector<int> order;
     order.reserve(b.nodes.size());
-    std::deque<int> queue{root_node};
+    std::deque<int> queue{root_node};  // cluster roots
     uint32_t next_unit = 0;
+    auto place = [&](int ni, uint32_t units) { b.nodes[ni].unit = next_unit; next_unit += units; order.push_back(ni); };
+    auto align4 = [&]() { next_unit = (next_unit + 3u) & ~3u; };
     while (!queue.empty()) {
-        int ni = queue.front();
+        const int ri = queue.front();
         queue.pop_front();
-        BuildNode &n = b.nodes[ni];
-        n.unit = next_unit;
-        next_unit += (n.axis < 0) ? 4u : 1u;
-        order.push_back(ni);
-        if (n.axis >= 0) { queue.push_back(n.left); queue.push_back(n.right); }
+        if (b.nodes[ri].axis < 0) { align4(); place(ri, 4u); continue; }  // a leaf root (a tree of one cell)
+        const int kids[2] = {b.nodes[ri].left, b.nodes[ri].right};
+        uint32_t inner_kids = 0;
+        for (int k : kids) if (b.nodes[k].axis >= 0) ++inner_kids;
+        if ((next_unit & 3u) + 1u + inner_kids > 4u) align4();        // the root and its inner children share a line
+        place(ri, 1u);
+        for (int k : kids) if (b.nodes[k].axis >= 0) place(k, 1u);
+        for (int k : kids) if (b.nodes[k].axis < 0) { align4(); place(k, 4u); }
+        for (int k : kids)
+            if (b.nodes[k].axis >= 0) { queue.push_back(b.nodes[k].left); queue.push_back(b.nodes[k].right); }  // grandchildren: new clusters
     }
     auto ref_of = [&](int ni) -> uint32_t {
         if (ni < 0) return HRT_KD_NIL;

@@ -100,8 +100,9 @@ typedef struct hrt_light {
  *   leaf  nodelet (4 units): { bmin.xyz, u32 tri_first | bmax.xyz, u32 tri_count |
  *                              rope[-x,+x,-y,+y] | rope[-z,+z], 0, 0 }
  * tri_first/tri_count index leaf_tris[] (triangle ids of the mesh).
- * Units are laid out breadth-first so a prefix of the array is the top of the
- * tree (that prefix is what the kernel stages into LDS). */
+ * Any numbering is valid.  The host builder keeps a node and its inner children inside one 64-byte line, starts leaves on
+ * 64-byte boundaries (unused padding units are zero) and emits these clusters breadth-first, so that a prefix of the
+ * array is the top of the tree (that prefix is what the kernels stage into LDS). */
 #define HRT_KD_LEAF 0x80000000u
 #define HRT_KD_NIL 0xFFFFFFFFu
 typedef struct hrt_kdunit {
