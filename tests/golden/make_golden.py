@@ -12,6 +12,8 @@ ref_kat.npz       inputs + outputs of the reference's OWN code (oracle/_ref/libr
 oracle_kat.npz    sphere / square known answers produced by the ORACLE (unpinned: Sphere.h / Square.h cannot be
                   compiled here); they tie the HIP device functions to the restatement.
 ref_ppm.json      reference PPM loader (imageLoader.cpp) w, h and FNV-1a checksum of every asset image.
+oracle_converged.npz  oracle means of 16 x 64 spp at 96x54 with the standard error per pixel, for the statistical check of
+                  the counter-based RNG streams (any seed must estimate the same image).
 oracle_images.npz oracle renders + AOVs of the config scenes at test size (fixed seed), so the GPU
                   box checks the HIP path against committed pixels as well as the live oracle.
 """
@@ -118,6 +120,20 @@ def main():
             imgs[f"{name}_aov_{k}"] = v_
         imgs[name + "_shape"] = np.array([w, h, spp, 1], np.int64)
     np.savez_compressed(os.path.join(HERE, "oracle_images.npz"), **imgs)
+
+    # converged low-resolution means with per-pixel sigma (SURVEY 8(c) fixture 5): 16 independent batches of 64 spp each
+    # (seeds 1000..1015) -> mean of the batch means and the standard error of that mean.  A render with ANY other seed must
+    # agree with these statistically (tests/test_gpu_parity.py::test_converged_means_agree_statistically).
+    st = {}
+    for name in ("cornell_box", "cornell_mesh", "random_spheres"):
+        w, h, batches, spp = 96, 54, 16, 64
+        host = hrt.HostScene().setup(name, w / h, 1); desc = host.flatten(); cam = hrt.default_camera(w / h)
+        sc = O.OracleScene(desc)
+        means = np.stack([sc.render(cam, w, h, spp, seed=1000 + b, threads=0).astype(np.float64) for b in range(batches)])
+        st[name + "_mean"] = means.mean(axis=0).astype(np.float32)
+        st[name + "_sem"] = (means.std(axis=0, ddof=1) / np.sqrt(batches)).astype(np.float32)
+        st[name + "_shape"] = np.array([w, h, batches, spp], np.int64)
+    np.savez_compressed(os.path.join(HERE, "oracle_converged.npz"), **st)
     print("golden vectors written")
 
 if __name__ == "__main__":
