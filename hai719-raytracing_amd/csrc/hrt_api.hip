@@ -837,7 +837,7 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
                              !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
-        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + sizeof(SpCtl) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4) +
+        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_STREAMS * sizeof(SpCtl) + sizeof(SpShared) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4) +
                                2048u + s->d.tab_rows * 16u;  // + the scene's per-object tables (stream_tables_fit)
         uint32_t per_cu = (64u * 4u * HRT_SP_MINW) / HRT_SP_WG;  // workgroups resident per CU (HRT_SP_MINW waves per SIMD in all) ...
         while (per_cu > 1u && 160u * 1024u / per_cu < fixed + 16u * 1024u) --per_cu;  // ... as far as the LDS pools allow

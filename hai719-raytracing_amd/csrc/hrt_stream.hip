@@ -58,6 +58,15 @@
 #ifndef HRT_SP_CYCLE_BOUND
 #define HRT_SP_CYCLE_BOUND (1u << 16)  // scheduler cycles one sample chunk of one work unit may take before the workgroup gives up
 #endif                                 // (a test build sets it to 3 to exercise the give-up path: Makefile, libhrt_var_bound.so)
+#ifndef HRT_SP_STREAMS
+#define HRT_SP_STREAMS 2   // independent path streams per workgroup (each with its own slots, queues and cycle counter).  With 2, a wave
+#endif                     // that runs out of chunks in one stream's cycle does not idle at a barrier: it arrives (an LDS counter) and goes
+                           // on with the other stream's cycle; the last wave to arrive prepares the stream's next cycle.  1 = one stream,
+                           // the same code with nothing to overlap (equivalent to a barrier per cycle)
+#ifndef HRT_SP_DEFER
+#define HRT_SP_DEFER 1     // 1: only whole chunks run while the fold still has paths to start (see the serial section)
+#endif
+#define HRT_SP_QCAP (HRT_SP_POOL / HRT_SP_STREAMS)  // slots, and entries per queue, of one stream
 #define HRT_SP_NQ 8        // queues: T0 T1 A0 A1 B0 B1 F0 F1 (A: sphere hits from the front, quad hits from the back;
                            // B: misses from the front, mesh hits from the back -- a path sits in exactly one place)
 
@@ -71,16 +80,25 @@ enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_HT, SP_HID, SP_HA0, SP_H
        SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB, SP_RI, SP_REM,  // rewritten by every hit visit: two aligned 16-byte stores
        SP_FIELDS };  // 32 dwords: one 128-byte record
 
-struct SpCtl {           // control block in LDS (24 dwords)
+struct SpCtl {           // control block of ONE stream in LDS (24 dwords)
     uint32_t cT[2], cF[2];   // queue fills, [parity]
     uint32_t cK[4][2];       // closest-hit queues by hit kind (0 miss, 1 sphere, 2 square, 3 mesh), [kind][parity]
     uint32_t cursor;         // chunk cursor of the running cycle
-    uint32_t ngen, gen_n0, paths_left;
-    uint32_t done, tile, parity, cycles;
-    uint32_t gave_up;        // the cycle bound tripped: the whole workgroup leaves the kernel
-    uint32_t pad[3];         // what follows the control block in LDS is read 16 bytes at a time
+    uint32_t ngen, gen_n0;   // new paths of the running cycle and the number of the first one
+    uint32_t done, parity, cycles;
+    uint32_t arrive;         // waves that have finished their part of a cycle of this stream, ever (monotonic)
+    uint32_t ready;          // number of the cycle whose control values above are valid (monotonic; waves wait for it)
+    uint32_t pad[4];
 };
-static_assert(sizeof(SpCtl) % 16 == 0, "the LDS regions behind the control block must stay 16-byte aligned");
+struct SpShared {        // what the streams of a workgroup share (8 dwords)
+    uint32_t gen_next;       // paths of the current fold handed out so far (atomic; may run past gen_total)
+    uint32_t gen_total;      // paths of the current fold
+    uint32_t tile;           // first tile slot of the work unit
+    uint32_t abort;          // a bound tripped: every wave leaves the scheduler, the workgroup leaves the kernel
+    uint32_t pad[4];
+};
+static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
+static_assert(HRT_SP_STREAMS == 1 || HRT_SP_STREAMS == 2, "one or two streams");
 
 static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
 static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_MAXG * 196 * 4 + 128 <= 160 * 1024,
@@ -88,8 +106,8 @@ static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HR
 
 struct SpLds {
     uint32_t *st;        // SP_FIELDS x POOL dwords
-    uint16_t *q;         // HRT_SP_NQ queues x POOL
-    SpCtl *ctl;
+    uint16_t *q;         // HRT_SP_NQ queues x HRT_SP_QCAP entries of the stream in hand (streams follow each other)
+    SpCtl *ctl;          // HRT_SP_STREAMS control blocks, then SpShared
     float *run;          // HRT_SP_MAXG x 64 x 3 running pixel sums of the unit's tiles, then HRT_SP_MAXG packed tile origins
 };
 
@@ -99,21 +117,21 @@ struct SpLds {
 #define SP_AT(field, slot) ((uint32_t)(field) * (uint32_t)HRT_SP_POOL + (slot))
 #endif
 #ifndef HRT_SP_NT
-#define HRT_SP_NT 0        // 1: path records are read and written with the non-temporal hint (they stream through the CU: a record is
+#define HRT_SP_NT 0        // bit 0: path records are read, bit 1: written with the non-temporal hint (they stream through the CU: a record is
 #endif                     //    touched once per visit, 512 KB per workgroup per cycle against a 32 KB L1)
 template <class T>
 struct SpRef {             // one dword of a path record
     T *p;
-    __device__ __forceinline__ operator T() const { return HRT_SP_NT ? __builtin_nontemporal_load(p) : *p; }
+    __device__ __forceinline__ operator T() const { return (HRT_SP_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
     __device__ __forceinline__ T operator=(T v) const {
-        if (HRT_SP_NT) __builtin_nontemporal_store(v, p);
+        if (HRT_SP_NT & 2) __builtin_nontemporal_store(v, p);
         else *p = v;
         return v;
     }
 };
 __device__ __forceinline__ SpRef<float> spf(const SpLds &L, int field, uint32_t slot) { return SpRef<float>{reinterpret_cast<float *>(L.st) + SP_AT(field, slot)}; }
 __device__ __forceinline__ SpRef<uint32_t> spu(const SpLds &L, int field, uint32_t slot) { return SpRef<uint32_t>{L.st + SP_AT(field, slot)}; }
-__device__ __forceinline__ uint16_t *spq(const SpLds &L, int which, uint32_t parity) { return L.q + (2 * which + parity) * HRT_SP_POOL; }
+__device__ __forceinline__ uint16_t *spq(const SpLds &L, int which, uint32_t parity) { return L.q + (2 * which + parity) * HRT_SP_QCAP; }
 
 // Wave-aggregated append of `slot` for the lanes with `want`: __ballot + one LDS atomic by the leader.
 __device__ __forceinline__ void sp_push(uint16_t *q, uint32_t *count, bool want, uint32_t slot) {
@@ -142,7 +160,7 @@ __device__ __forceinline__ void sp_push_hit(const SpLds &L, SpCtl &C, uint32_t o
         if (want && kind == k) {
             const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             uint16_t *q = spq(L, (k == 1u || k == 2u) ? 1 : 2, out);
-            q[(k == 1u || k == 0u) ? pos : (uint32_t)HRT_SP_POOL - 1u - pos] = (uint16_t)slot;
+            q[(k == 1u || k == 0u) ? pos : (uint32_t)HRT_SP_QCAP - 1u - pos] = (uint16_t)slot;
         }
     }
 }
@@ -183,7 +201,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     L.q = reinterpret_cast<uint16_t *>(L.st + SP_FIELDS * HRT_SP_POOL);
 #endif
     L.ctl = reinterpret_cast<SpCtl *>(L.q + HRT_SP_NQ * HRT_SP_POOL);
-    L.run = reinterpret_cast<float *>(L.ctl + 1);
+    SpShared &SH = *reinterpret_cast<SpShared *>(L.ctl + HRT_SP_STREAMS);
+    L.run = reinterpret_cast<float *>(&SH + 1);
     uint32_t *tile_xy = reinterpret_cast<uint32_t *>(L.run + HRT_SP_MAXG * 192);  // x0 | y0 << 16 per tile of the unit, ~0: no tile
     float *s_lut = reinterpret_cast<float *>(tile_xy + HRT_SP_MAXG);     // the u8 -> float tables (512 floats)
     float4 *s_tabs = reinterpret_cast<float4 *>(s_lut + 512);            // 16-byte aligned: every size above is a multiple of 16
@@ -207,14 +226,17 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         for (uint32_t i = tid; i < tab_rows; i += HRT_SP_WG) s_tabs[i] = ld(g_tabs, i);
         if (tid < 512u) s_lut[tid] = c_u8_lut[tid];
     }
-    SpCtl &C = *L.ctl;
-    if (tid == 0) {
-        C.cT[0] = C.cT[1] = 0;
-        for (int k = 0; k < 4; ++k) C.cK[k][0] = C.cK[k][1] = 0;
-        C.cF[0] = HRT_SP_POOL; C.cF[1] = 0;
-        C.parity = 0; C.cycles = 0; C.done = 0; C.gave_up = 0;
+    uint16_t *const q_all = L.q;
+    if (tid < HRT_SP_STREAMS) {
+        SpCtl &C0 = L.ctl[tid];
+        C0.cT[0] = C0.cT[1] = 0;
+        for (int k = 0; k < 4; ++k) C0.cK[k][0] = C0.cK[k][1] = 0;
+        C0.cF[0] = HRT_SP_QCAP; C0.cF[1] = 0;
+        C0.parity = 1; C0.cycles = 0; C0.done = 0; C0.arrive = 0; C0.ready = 0; C0.cursor = 0; C0.ngen = 0; C0.gen_n0 = 0;
+        if (tid == 0) { SH.gen_next = 0; SH.gen_total = 0; SH.tile = 0; SH.abort = 0; }
     }
-    for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG) spq(L, 3, 0)[i] = (uint16_t)i;  // every slot free
+    for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG)  // every slot free, in its stream's free queue (parity 0)
+        q_all[(i / HRT_SP_QCAP) * (HRT_SP_NQ * HRT_SP_QCAP) + (2 * 3 + 0) * HRT_SP_QCAP + (i % HRT_SP_QCAP)] = (uint16_t)i;
     const bool has_mesh = cx.S->n_meshes != 0u;
     const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
     float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNIT * 3u);
@@ -236,15 +258,15 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #define SEG(k) do { } while (0)
 #endif
 #ifdef HRT_SP_DEBUG
-    unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0;
+    unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0, dbg_wait = 0, dbg_drain = 0;
     unsigned long long dbg_class[6] = {0, 0, 0, 0, 0, 0};  // clocks in T, mesh-hit, sphere-hit, square-hit, miss, G chunks
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
 #endif
     for (;;) {  // tiles
         __syncthreads();
-        if (tid == 0) C.tile = atomicAdd(R.tile_counter, G);
+        if (tid == 0) SH.tile = atomicAdd(R.tile_counter, G);
         __syncthreads();
-        const uint32_t j = SP_UNI(C.tile);  // first tile slot of the unit
+        const uint32_t j = SP_UNI(SH.tile);  // first tile slot of the unit
         if (j >= R.tiles_owned) break;  // finite queue: every workgroup gets here
         if (tid < G) {
             uint32_t xy = 0xFFFFFFFFu;
@@ -265,35 +287,114 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         for (uint32_t s0 = 0; s0 < R.spp; s0 += per_fold) {  // sample chunks of the unit
             const uint32_t ns = min(per_fold, R.spp - s0);
             __syncthreads();
-            if (tid == 0) { C.paths_left = upix * ns; C.gen_n0 = 0; C.cycles = 0; }
-            for (;;) {  // cycles
-                __syncthreads();
-#ifdef HRT_SP_DEBUG
-                const unsigned long long dbg_s0 = __builtin_readcyclecounter();
+            // ---- the scheduler of one fold: HRT_SP_STREAMS streams of cycles, no barrier inside.
+            // A stream's cycle k: its control block (queue fills, new paths) is valid once ready == k; the waves pull its chunks
+            // from one cursor; a wave that finds none left waits for its own stores, ARRIVES (arrive += 1) and moves to the other
+            // stream.  The wave whose arrival completes the cycle (arrive == waves x k) runs the serial section -- it hands out
+            // new paths, swaps the queue buffers, carries the unused free slots over -- and publishes ready = k + 1.  Waves visit
+            // the streams in the fixed order A1 B1 A2 B2 ...; a stage only ever waits for all waves to have passed the previous
+            // stage of the same stream, so there is no cyclic wait.  Every wait is bounded (abort -> HRT_ERR_DEVICE on the host).
+            auto serial_section = [&](SpCtl &C, uint16_t *qs) {  // one whole wave; control values by lane 0
+                const uint32_t par = SP_UNI(C.parity) ^ 1u;  // the buffers the finished cycle appended to become the input
+                const uint32_t free_in = SP_UNI(C.cF[par]);
+#if HRT_SP_DEFER
+                const uint32_t want = free_in & ~63u;  // whole chunks of new paths only (the last paths of the fold come as they are)
+#else
+                const uint32_t want = free_in;
 #endif
-                if (tid == 0) {
-                    const uint32_t par = C.parity;
-                    const uint32_t ngen = min(C.cF[par], C.paths_left);
-                    C.ngen = ngen;
-                    C.cursor = 0;
-                    C.cT[par ^ 1u] = 0;
-                    uint32_t waiting = C.cT[par];
-                    for (int k = 0; k < 4; ++k) { C.cK[k][par ^ 1u] = 0; waiting += C.cK[k][par]; }
-                    C.cF[par ^ 1u] = C.cF[par] - ngen;  // the unused free slots carry over, S appends after them
-                    C.done = (ngen == 0u && waiting == 0u) ? 1u : 0u;
-                    if (++C.cycles > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
-                        // The frame is lost: flag it for the host (hrt_check_last_launch / hrt_render return HRT_ERR_DEVICE)
-                        // and take the whole workgroup out of the kernel -- its queues and pool hold paths in flight, so
-                        // it must not start another unit from that state.  The other workgroups finish their tiles.
-                        if (R.stamps) __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        C.done = 1u;
-                        C.gave_up = 1u;
+                uint32_t old = 0;
+                if (lane == 0) old = atomicAdd(&SH.gen_next, want);
+                old = SP_UNI(old);
+                const uint32_t total_paths = SP_UNI(SH.gen_total);
+                const uint32_t ngen = old >= total_paths ? 0u : min(want, total_paths - old);
+                uint16_t *qFi = qs + (2 * 3 + par) * HRT_SP_QCAP, *qFo = qs + (2 * 3 + (par ^ 1u)) * HRT_SP_QCAP;
+                for (uint32_t i = lane; i < free_in - ngen; i += 64u) qFo[i] = qFi[ngen + i];  // carry unused free slots
+                // While the fold still has paths to start, a queue's last PARTIAL chunk waits for the next cycle (it moves to the front
+                // of the output queue, so the oldest entries go first): the paths are independent and the fold is ordered, so when a
+                // path is advanced changes nothing -- and the chunks that do run have all 64 lanes filled.  Once every path of the
+                // fold has been started, everything runs (the stream drains).
+                const bool defer = HRT_SP_DEFER && old + ngen < total_paths;
+                const uint32_t cT = SP_UNI(C.cT[par]), rT = defer ? (cT & 63u) : 0u;
+                if (lane < rT) qs[(2 * 0 + (par ^ 1u)) * HRT_SP_QCAP + lane] = qs[(2 * 0 + par) * HRT_SP_QCAP + cT - rT + lane];
+                uint32_t cKv[4], rK[4], waiting = cT;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cKv[k] = SP_UNI(C.cK[k][par]);
+                    rK[k] = defer ? (cKv[k] & 63u) : 0u;
+                    waiting += cKv[k];
+                    const int which = (k == 1 || k == 2) ? 1 : 2;  // the addressing of sp_push_hit: kinds 1 and 0 from the front, 2 and 3 from the back
+                    const bool back = !(k == 1 || k == 0);
+                    const uint16_t *qi = qs + (2 * which + par) * HRT_SP_QCAP;
+                    uint16_t *qo = qs + (2 * which + (par ^ 1u)) * HRT_SP_QCAP;
+                    if (lane < rK[k]) {
+                        const uint32_t e = cKv[k] - rK[k] + lane;
+                        qo[back ? (uint32_t)HRT_SP_QCAP - 1u - lane : lane] = qi[back ? (uint32_t)HRT_SP_QCAP - 1u - e : e];
                     }
                 }
-                __syncthreads();
-                if (SP_UNI(C.done)) break;
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { C.cK[k][par] = cKv[k] - rK[k]; C.cK[k][par ^ 1u] = rK[k]; }
+                    C.cT[par] = cT - rT;
+                    C.cT[par ^ 1u] = rT;
+                    C.cF[par ^ 1u] = free_in - ngen;  // the unused free slots carry over, freed slots are appended after them
+                    C.ngen = ngen; C.gen_n0 = old; C.cursor = 0; C.parity = par;
+                    C.done = (ngen == 0u && waiting == 0u) ? 1u : 0u;  // nothing in flight and nothing left to start: the stream has drained
+                    if (++C.cycles > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
+                        // The frame is lost: flag it for the host (hrt_check_last_launch / hrt_render return HRT_ERR_DEVICE) and take
+                        // the whole workgroup out of the kernel -- its queues and pool hold paths in flight, so it must not start
+                        // another unit from that state.  The other workgroups finish their tiles.
+                        if (R.stamps) __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // control block and free list are in LDS before the cycle is announced
+                if (lane == 0) __hip_atomic_store(&C.ready, C.ready + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            if (tid < 64u) {  // wave 0 opens the fold: cycle 1 of every stream
+                if (lane == 0) { SH.gen_next = 0; SH.gen_total = upix * ns; }
+                for (uint32_t st = 0; st < HRT_SP_STREAMS; ++st) {
+                    SpCtl &C = L.ctl[st];
+                    if (lane == 0) { C.cycles = 0; C.arrive = 0; C.ready = 0; }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // between folds every path is free again: the free list of the last input parity holds every slot of the stream
+                    serial_section(C, q_all + st * (HRT_SP_NQ * HRT_SP_QCAP));
+                }
+            }
+            __syncthreads();
+            uint32_t kcyc[HRT_SP_STREAMS], fin_mask = 0u;
+            for (uint32_t st = 0; st < HRT_SP_STREAMS; ++st) kcyc[st] = 1u;
+            for (uint32_t round = 0;; ++round) {  // stages A1 B1 A2 B2 ... of this wave
+                const uint32_t st = HRT_SP_STREAMS == 1 ? 0u : (round & 1u);
+                if (fin_mask == (1u << HRT_SP_STREAMS) - 1u) break;
+                if (fin_mask & (1u << st)) continue;
+                SpCtl &C = L.ctl[st];
+                L.q = q_all + st * (HRT_SP_NQ * HRT_SP_QCAP);
+                {   // wait for the control block of this stage (normally there already)
+#ifdef HRT_SP_DEBUG
+                    const unsigned long long dbg_q0 = __builtin_readcyclecounter();
+#endif
+                    uint32_t spins = 0, aborted = 0;
+                    while (SP_UNI(__hip_atomic_load(&C.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kcyc[st]) {
+                        __builtin_amdgcn_s_sleep(8);
+                        aborted = SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if (aborted) break;
+                        if (++spins > (1u << 24)) {  // seconds: nothing legitimate takes that long
+                            if (lane == 0) {
+                                if (R.stamps) __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            aborted = 1u;
+                            break;
+                        }
+                    }
+#ifdef HRT_SP_DEBUG
+                    dbg_wait += __builtin_readcyclecounter() - dbg_q0;
+#endif
+                    if (aborted || SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+                }
+                if (SP_UNI(C.done)) { fin_mask |= 1u << st; continue; }
                 const uint32_t parity = SP_UNI(C.parity);
-                const uint32_t ngen = SP_UNI(C.ngen), cFin = SP_UNI(C.cF[parity]), n0 = SP_UNI(C.gen_n0);
+                const uint32_t ngen = SP_UNI(C.ngen), n0 = SP_UNI(C.gen_n0);
                 const uint32_t cTin = SP_UNI(C.cT[parity]);
                 const uint32_t cK0 = SP_UNI(C.cK[0][parity]), cK1 = SP_UNI(C.cK[1][parity]), cK2 = SP_UNI(C.cK[2][parity]),
                                cK3 = SP_UNI(C.cK[3][parity]);
@@ -304,10 +405,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 uint16_t *qAi = spq(L, 1, parity), *qBi = spq(L, 2, parity);
                 uint16_t *qFi = spq(L, 3, parity), *qFo = spq(L, 3, parity ^ 1u);
                 uint32_t *cTo = &C.cT[parity ^ 1u], *cFo = &C.cF[parity ^ 1u];
-                for (uint32_t i = tid; i < cFin - ngen; i += HRT_SP_WG) qFo[i] = qFi[ngen + i];  // carry unused free slots
 #ifdef HRT_SP_DEBUG
                 const unsigned long long dbg_w0 = __builtin_readcyclecounter();
-                dbg_serial += dbg_w0 - dbg_s0; ++dbg_cycles;
+                ++dbg_cycles;
 #endif
 
                 for (;;) {  // chunks of this cycle: T first (longest), then S, then G
@@ -410,7 +510,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 freed = true;
                             }
                         } else if (act) {
-                            slot = qHi[from_back ? (uint32_t)HRT_SP_POOL - 1u - e : e] & (HRT_SP_POOL - 1u);
+                            slot = qHi[from_back ? (uint32_t)HRT_SP_QCAP - 1u - e : e] & (HRT_SP_POOL - 1u);
                             ray = sp_load_ray(L, slot);
                             const Hit h = sp_load_hit(L, slot);
                             f3 thr = mk(spf(L, SP_TR, slot), spf(L, SP_TG, slot), spf(L, SP_TB, slot));
@@ -486,12 +586,30 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #ifdef HRT_SP_DEBUG
                 dbg_work += __builtin_readcyclecounter() - dbg_w0;
 #endif
-                __syncthreads();
-                if (tid == 0) { C.paths_left -= ngen; C.gen_n0 += ngen; C.parity = parity ^ 1u; }
+                // this wave's part of the cycle is done: its records are in memory and its queue entries in LDS before it arrives
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                uint32_t arrived = 0;
+                if (lane == 0) arrived = __hip_atomic_fetch_add(&C.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                arrived = SP_UNI(arrived);
+#ifdef HRT_SP_DEBUG
+                const unsigned long long dbg_s0 = __builtin_readcyclecounter();
+#endif
+                if (arrived + 1u == (HRT_SP_WG / 64u) * kcyc[st]) serial_section(C, L.q);  // the last wave prepares the stream's next cycle
+#ifdef HRT_SP_DEBUG
+                dbg_serial += __builtin_readcyclecounter() - dbg_s0;
+#endif
+                ++kcyc[st];
             }
-            if (SP_UNI(C.gave_up)) return;  // uniform: written by thread 0 before the barrier every thread passed to get here
-            // the chunk has drained: fold its samples into the pixel sums in sample order (main.cpp:193)
+            L.q = q_all;
+#ifdef HRT_SP_DEBUG
+            const unsigned long long dbg_d0 = __builtin_readcyclecounter();
+#endif
             __syncthreads();
+#ifdef HRT_SP_DEBUG
+            dbg_drain += __builtin_readcyclecounter() - dbg_d0;
+#endif
+            if (SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;  // uniform: read behind the barrier
+            // the fold has drained: its samples go into the pixel sums in sample order (main.cpp:193)
             // Plain loads: the scratch was written by waves of THIS workgroup (one CU), every one of which passed the
             // barrier above after its stores (s_waitcnt vmcnt(0) + s_barrier); a CU's vector L1 is coherent with that CU's
             // own stores (it is only other CUs' stores it never sees), which is also what the path pool's plain loads and
@@ -532,6 +650,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         atomicAdd(R.stamps + 0, dbg_work); atomicAdd(R.stamps + 1, __builtin_readcyclecounter() - dbg_t0);
         atomicAdd(R.stamps + 2, dbg_cycles); atomicAdd(R.stamps + 3, dbg_chunks); atomicAdd(R.stamps + 4, dbg_serial);
         for (int k = 0; k < 6; ++k) atomicAdd(R.stamps + 5 + k, dbg_class[k]);  // [5..10] clocks per chunk class
+        atomicAdd(R.stamps + 11, dbg_wait); atomicAdd(R.stamps + 12, dbg_drain);  // waiting for a stream's next cycle; at the barrier that ends a fold
     }
 #endif
 #undef SP_UNI

@@ -1,4 +1,1 @@
-python -m pytest tests -m gpu -q > gpurun_out/t19.log 2>&1; tail -3 gpurun_out/t19.log
-bash tools/profile.sh r02 > gpurun_out/profile_r02.log 2>&1; tail -14 gpurun_out/profile_r02.log
-cp gpurun_out/prof_r02/r02_pmc.json gpurun_out/prof_r02/r02_kernel_stats.csv profiles/
-python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r02b.log 2>&1; tail -1 gpurun_out/bench_r02b.log
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/t29.log 2>&1; tail -5 gpurun_out/t29.log
