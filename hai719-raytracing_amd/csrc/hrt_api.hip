@@ -7,6 +7,7 @@
 #include "hrt_output.hip"
 #include "hrt_kat.hip"
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -525,15 +526,21 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         }
         dm.tri_base = tri_base;
         dm.n_soup = M.n_leaf_tris;
-        // Irregular triangles (include/hrt.h hrt_tri_exception): grouped by reference leaf box.  Each distinct box becomes a
-        // leaf entry {box lo, first soup slot} {box hi, count} whose triangles' rows sit contiguously behind the mesh's
-        // leaf-ordered soup (a triangle held by several boxes is folded once per box: a box hit then reads one run of rows);
-        // a bounding hierarchy over the boxes, threaded depth-first ({lo', HRT_EXC_INNER} {hi', skip}), lets a ray that
-        // passes none of them leave after one test.  Inner boxes are padded: they only cull, the leaf boxes decide.
+        // Irregular triangles (include/hrt.h hrt_tri_exception), grouped by TRIANGLE.  The reference tests such a triangle when
+        // the ray passes a leaf box that holds it (KDTree.cpp:32-46), and the outcome of the triangle test does not depend on
+        // which box that was: so each irregular triangle is folded once (its rows sit behind the mesh's leaf-ordered soup) and
+        // tested at most once per ray, and only a ray that HITS it closer than the best so far goes through the list of its
+        // reference boxes (exact AABB.h:48-65 arithmetic) to learn whether the reference would have tested it at all.
+        // Entries, 2 rows each, threaded depth-first:
+        //   inner   {lo', HRT_EXC_INNER} {hi', skip}     padded bounds of a subtree: only culls
+        //   leaf    {cull lo, soup slot} {cull hi, nb}   then nb box entries {box lo, 0} {box hi, 0} the walk jumps over
+        // The cull box of a well-conditioned triangle is its own padded bounds (an accepted hit point lies in the triangle up to
+        // the rounding of the barycentric solve, ~1e-7 / sin^2); a sliver's barycentric test accepts points anywhere in its
+        // plane, so its cull box is the padded union of its reference boxes (a ray that passes none of them is not tested).
         dm.exc_base = (uint32_t)(exceptions.size() / 2);
         dm.n_exc = 0;
         if (M.n_exceptions) {
-            struct Group { float lo[3], hi[3]; std::vector<uint32_t> tris; };
+            struct Group { float lo[3], hi[3]; uint32_t tri; std::vector<std::array<float, 6>> boxes; };
             std::vector<Group> groups;
             {
                 std::vector<uint32_t> order(M.n_exceptions);
@@ -541,17 +548,47 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                     if (M.exceptions[k].triangle >= M.n_triangles) return fail(HRT_ERR_INVALID, "exception triangle id out of range");
                     order[k] = k;
                 }
-                auto box_less = [&](uint32_t x, uint32_t y) { return std::memcmp(M.exceptions[x].box_min, M.exceptions[y].box_min, 24) < 0; };  // box_min, box_max are adjacent
                 static_assert(offsetof(hrt_tri_exception, box_max) == offsetof(hrt_tri_exception, box_min) + 12, "box_min and box_max are contiguous");
-                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return box_less(x, y) || (!box_less(y, x) && M.exceptions[x].triangle < M.exceptions[y].triangle); });
-                for (uint32_t k : order) {
-                    const hrt_tri_exception &e = M.exceptions[k];
-                    if (groups.empty() || std::memcmp(groups.back().lo, e.box_min, 12) != 0 || std::memcmp(groups.back().hi, e.box_max, 12) != 0) {
+                auto box_cmp = [&](uint32_t x, uint32_t y) { return std::memcmp(M.exceptions[x].box_min, M.exceptions[y].box_min, 24); };
+                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                    return M.exceptions[x].triangle < M.exceptions[y].triangle || (M.exceptions[x].triangle == M.exceptions[y].triangle && box_cmp(x, y) < 0);
+                });
+                for (size_t q = 0; q < order.size(); ++q) {
+                    const hrt_tri_exception &e = M.exceptions[order[q]];
+                    if (groups.empty() || groups.back().tri != e.triangle) {
                         groups.emplace_back();
-                        std::memcpy(groups.back().lo, e.box_min, 12);
-                        std::memcpy(groups.back().hi, e.box_max, 12);
+                        groups.back().tri = e.triangle;
+                    } else if (box_cmp(order[q - 1], order[q]) == 0) {
+                        continue;  // the same pair twice
                     }
-                    if (groups.back().tris.empty() || groups.back().tris.back() != e.triangle) groups.back().tris.push_back(e.triangle);
+                    std::array<float, 6> bx;
+                    std::memcpy(bx.data(), e.box_min, 24);
+                    groups.back().boxes.push_back(bx);
+                }
+                for (Group &g : groups) {
+                    double c[3][3];
+                    for (int j = 0; j < 3; ++j) {
+                        const float *pp = M.positions + 3 * (size_t)M.indices[3 * (size_t)g.tri + j];
+                        for (int a = 0; a < 3; ++a) c[j][a] = (double)(pp[a] * HRT_TRIANGLE_SCALING);
+                    }
+                    double e1[3], e2[3], cr[3];
+                    for (int a = 0; a < 3; ++a) { e1[a] = c[1][a] - c[0][a]; e2[a] = c[2][a] - c[0][a]; }
+                    cr[0] = e1[1] * e2[2] - e1[2] * e2[1]; cr[1] = e1[2] * e2[0] - e1[0] * e2[2]; cr[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                    const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+                    const double sin2 = (cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]) / (l1 * l2);
+                    const bool own_bounds = std::isfinite(sin2) && sin2 >= 1e-2;  // NaN (zero edge): the union of the boxes
+                    for (int a = 0; a < 3; ++a) {
+                        double lo = INFINITY, hi = -INFINITY;
+                        if (own_bounds) {
+                            for (int j = 0; j < 3; ++j) { lo = std::min(lo, c[j][a]); hi = std::max(hi, c[j][a]); }
+                        } else {
+                            for (const auto &bx : g.boxes) { lo = std::min(lo, (double)bx[a]); hi = std::max(hi, (double)bx[3 + a]); }
+                        }
+                        double ext = 0.0;
+                        for (int x = 0; x < 3; ++x) ext = std::max(ext, std::max(std::fabs(e1[x]), std::fabs(e2[x])));
+                        const double pad = (own_bounds ? 1e-3 * ext : 0.0) + 1e-4 * std::max(1.0, std::max(std::fabs(lo), std::fabs(hi)));
+                        g.lo[a] = (float)(lo - pad); g.hi[a] = (float)(hi + pad);
+                    }
                 }
             }
             const size_t first_entry = exceptions.size() / 2;
@@ -564,10 +601,14 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 void run(size_t lo, size_t hi) {
                     if (hi - lo == 1) {
                         const Group &b = g[lo];
-                        const uint32_t first = (uint32_t)(tris.size() / HRT_TRI_ROWS);
-                        for (uint32_t t : b.tris) push_triangle(t);
-                        out.push_back(make_float4(b.lo[0], b.lo[1], b.lo[2], as_float(first)));
-                        out.push_back(make_float4(b.hi[0], b.hi[1], b.hi[2], as_float((uint32_t)b.tris.size())));
+                        const uint32_t slot = (uint32_t)(tris.size() / HRT_TRI_ROWS);
+                        push_triangle(b.tri);
+                        out.push_back(make_float4(b.lo[0], b.lo[1], b.lo[2], as_float(slot)));
+                        out.push_back(make_float4(b.hi[0], b.hi[1], b.hi[2], as_float((uint32_t)b.boxes.size())));
+                        for (const auto &bx : b.boxes) {
+                            out.push_back(make_float4(bx[0], bx[1], bx[2], 0.f));
+                            out.push_back(make_float4(bx[3], bx[4], bx[5], 0.f));
+                        }
                         return;
                     }
                     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -583,7 +624,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                     const size_t mid = lo + (hi - lo) / 2;
                     std::nth_element(g.begin() + lo, g.begin() + mid, g.begin() + hi, [axis](const Group &x, const Group &y) {
                         const float cx = x.lo[axis] + x.hi[axis], cy = y.lo[axis] + y.hi[axis];
-                        return cx < cy || (cx == cy && std::memcmp(x.lo, y.lo, 12) < 0);
+                        return cx < cy || (cx == cy && x.tri < y.tri);
                     });
                     const size_t self = out.size();
                     float pmin[3], pmax[3];

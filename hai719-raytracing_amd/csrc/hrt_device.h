@@ -16,9 +16,9 @@
 //   materials     8 float4 rows per material, read per lane at the closest hit (rows 6, 7: geometry of its texture / normal map)
 //   meshes        DMesh records (wave-uniform)
 //   kd units      uint4 nodelets (include/hrt.h), refs rebased to the global array
-//   exceptions    irregular triangles (include/hrt.h hrt_tri_exception) by distinct reference leaf box: leaf entry {box lo, first soup
-//                 slot} {box hi, count} (the triangles' rows sit contiguously behind the mesh's leaf-ordered soup), bounding entry
-//                 {lo, HRT_EXC_INNER} {hi, skip}, threaded depth-first
+//   exceptions    irregular triangles (include/hrt.h hrt_tri_exception), one leaf entry each: {cull lo, soup slot} {cull hi, nb} followed by
+//                 its nb reference leaf boxes {lo, 0} {hi, 0} (its rows sit behind the mesh's leaf-ordered soup); bounding entry
+//                 {lo, HRT_EXC_INNER} {hi, skip}; threaded depth-first
 //   triangles     leaf-ordered soup in two arrays by slot: planes {n, D} (16 B: the planes of a leaf's triangles share a cache line) and
 //                 rows {c0, id} {e1, d00} {e2, d01} {d11, denom, -, -} (one 64-byte line, read only when the plane is hit in front)
 //                 (Triangle.h:32-37, 62-75 constants folded on the host in the reference's arithmetic)

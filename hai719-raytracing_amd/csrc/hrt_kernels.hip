@@ -367,16 +367,17 @@ __device__ __forceinline__ uint32_t tri_test_run(const Soup &sp, uint32_t first,
 
 // The IRREGULAR triangles of a mesh (include/hrt.h hrt_tri_exception; host/ref_tree.h): triangles the reference's builder
 // drops in part of its tree, and slivers whose barycentric test accepts phantom points.  They are not in the rope tree;
-// each is tested exactly when the reference would test it -- when the ray passes the box of a reference leaf that holds
-// it (KDTree.cpp:32-46 with AABB.h:48-65; EXACT: the fp64 form only, else the fp32 filter in front of it).
+// each counts exactly when the reference would test it -- when the ray passes the box of a reference leaf that holds
+// it (KDTree.cpp:32-46 with AABB.h:48-65; EXACT: the fp64 form only, else the fp32 filter in front of it).  The triangle
+// test comes FIRST (its outcome does not depend on the box) and the boxes are consulted only for a hit closer than the best.
 template <bool EXACT, class EP, class MP>
 __device__ __forceinline__ bool mesh_exceptions_walk(cscene S, EP ex_all, MP M, const Ray &ray, f3 inv, float &best_t, uint32_t &best_tri, float &bu, float &bv) {
     const uint32_t n = M->n_exc;
     bool found = false;
     const EP ex = ex_all + 2u * M->exc_base;
     const Soup sp = soup_of(S);
-    // entries {box lo, first soup slot | HRT_EXC_INNER} {box hi, count | skip}: the distinct reference leaf boxes under a
-    // bounding hierarchy threaded depth-first (hrt_api.hip scene_create_impl)
+    // entries (hrt_api.hip scene_create_impl): {lo', HRT_EXC_INNER} {hi', skip} bounds of a subtree; {cull lo, soup slot} {cull hi, nb}
+    // one irregular triangle, followed by its nb reference leaf boxes {lo, 0} {hi, 0}
     for (uint32_t i = 0; i < n;) {
         const float4 lo = ld(ex, 2u * i), hi = ld(ex, 2u * i + 1u);
         const uint32_t first = __float_as_uint(lo.w), cnt = __float_as_uint(hi.w);
@@ -385,10 +386,21 @@ __device__ __forceinline__ bool mesh_exceptions_walk(cscene S, EP ex_all, MP M, 
         ++i;
         if (first == HRT_EXC_INNER) {  // bounds of a subtree: only culls (never in the proof builds)
             if (!EXACT && gate_filter(b, ray, inv) < 0) i = cnt;
-        } else if (mesh_gate_box<EXACT>(b, ray, inv)) {  // the ray passes this reference leaf: its irregular triangles are tested
-            for (uint32_t k = 0; k < cnt;)  // a run can be long (a leaf the reference's builder gave up on): planes are requested in batches
-                k = tri_test_run(sp, first, cnt, k, ray, best_t, best_tri, bu, bv, found);
+            continue;
         }
+        const uint32_t boxes = i;
+        i += cnt;
+        if (!EXACT && gate_filter(b, ray, inv) < 0) continue;  // the cull box (padded; never in the proof builds)
+        float t = best_t, u = 0.f, v = 0.f;
+        if (!tri_test(sp, first, ray, t, u, v)) continue;      // Triangle.h:77-126 and the leaf's strict `<` (KDTree.cpp:44)
+        bool tested = false;  // would the reference have tested it: does the ray pass a reference leaf that holds it (AABB.h:48-65)
+        for (uint32_t j = 0; j < cnt && !tested; ++j) {
+            const float4 bl = ld(ex, 2u * (boxes + j)), bh = ld(ex, 2u * (boxes + j) + 1u);
+            GateBox rb;
+            rb.l[0] = bl.x; rb.l[1] = bl.y; rb.l[2] = bl.z; rb.h[0] = bh.x; rb.h[1] = bh.y; rb.h[2] = bh.z;
+            tested = mesh_gate_box<EXACT>(rb, ray, inv);
+        }
+        if (tested) { best_t = t; bu = u; bv = v; best_tri = first; found = true; }
     }
     return found;
 }

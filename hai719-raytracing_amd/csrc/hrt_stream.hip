@@ -63,6 +63,9 @@
 #endif                     // that runs out of chunks in one stream's cycle does not idle at a barrier: it arrives (an LDS counter) and goes
                            // on with the other stream's cycle; the last wave to arrive prepares the stream's next cycle.  1 = one stream,
                            // the same code with nothing to overlap (equivalent to a barrier per cycle)
+#ifndef HRT_SP_THALF
+#define HRT_SP_THALF 0     // experiment: T chunks of 32 paths (half the lanes idle) -- latency- or throughput-bound?
+#endif
 #ifndef HRT_SP_DEFER
 #define HRT_SP_DEFER 1     // 1: only whole chunks run while the fold still has paths to start (see the serial section)
 #endif
@@ -399,7 +402,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 const uint32_t cK0 = SP_UNI(C.cK[0][parity]), cK1 = SP_UNI(C.cK[1][parity]), cK2 = SP_UNI(C.cK[2][parity]),
                                cK3 = SP_UNI(C.cK[3][parity]);
                 // chunk ranges of this cycle: T (longest) first, then mesh, sphere, square hits, misses, new paths last
-                const uint32_t nT = (cTin + 63u) >> 6, e3 = nT + ((cK3 + 63u) >> 6), e1 = e3 + ((cK1 + 63u) >> 6),
+                const uint32_t nT = HRT_SP_THALF ? (cTin + 31u) >> 5 : (cTin + 63u) >> 6, e3 = nT + ((cK3 + 63u) >> 6), e1 = e3 + ((cK1 + 63u) >> 6),
                                e2 = e1 + ((cK2 + 63u) >> 6), e0 = e2 + ((cK0 + 63u) >> 6), nG = (ngen + 63u) >> 6, total = e0 + nG;
                 uint16_t *qTi = spq(L, 0, parity), *qTo = spq(L, 0, parity ^ 1u);
                 uint16_t *qAi = spq(L, 1, parity), *qBi = spq(L, 2, parity);
@@ -422,8 +425,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #endif
                     if (c < nT) {
                         // ---------------- T: mesh walk
-                        const uint32_t e = c * 64u + lane;
-                        const bool act = e < cTin;
+                        const uint32_t e = HRT_SP_THALF ? c * 32u + lane : c * 64u + lane;
+                        const bool act = e < cTin && (!HRT_SP_THALF || lane < 32u);
                         uint32_t slot = 0, kind = 0, pm = 0, ref_in = HRT_KD_NIL, pm_before = 0;
                         bool walked = false;
                         Ray ray;
