@@ -102,6 +102,7 @@ struct SpShared {        // what the streams of a workgroup share (8 dwords)
 };
 static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
 static_assert(HRT_SP_STREAMS == 1 || HRT_SP_STREAMS == 2, "one or two streams");
+static_assert(HRT_SP_QCAP >= 512, "deferring partial chunks needs a queue that can hold a whole chunk whenever fewer than 64 slots are free (6 queues x 63 < QCAP - 64)");
 
 static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
 static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_MAXG * 196 * 4 + 128 <= 160 * 1024,
