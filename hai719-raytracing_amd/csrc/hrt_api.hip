@@ -462,51 +462,89 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         units.resize((units.size() + 3u) & ~(size_t)3u, make_uint4(0, 0, 0, 0));  // every mesh's nodelets start on a 64-byte line (the host aligns clusters and leaves)
         const uint32_t unit_base = (uint32_t)units.size();
         const uint32_t tri_base = (uint32_t)(tris.size() / HRT_TRI_ROWS);
-        auto rebase = [&](uint32_t ref, bool &ok) -> uint32_t {
-            if (ref == HRT_KD_NIL) return ref;
+        // The caller's tree (include/hrt.h: 16-byte inner nodelets, 64-byte leaves, any numbering) is re-laid for the walk:
+        //   inner nodes become TREELETS of two levels in 32 bytes  {split, left child's split, right child's split, axes}
+        //   {refs of the four grandchildren}  (axes: 2 bits per node; 3 = the child is a leaf, both exits of its pair hold its ref),
+        //   one for the root, one for every grandchild that is an inner node and one for every inner node a rope points at --
+        //   a walk then descends two levels per round trip (csrc/hrt_kernels.hip kd_descend);
+        //   leaves keep their four units {lo, first} {hi, count} {ropes -x +x -y +y} {ropes -z +z}, refs translated, on 64-byte lines.
+        // Numbering is breadth-first from the root, so a prefix of the array is the top of the tree (what the kernels stage in LDS).
+        // Only reachable, well-formed nodelets are accepted.
+        auto in_range = [&](uint32_t ref) -> bool {
+            if (ref == HRT_KD_NIL) return true;
             const uint32_t idx = ref & ~HRT_KD_LEAF;
-            const uint32_t need = (ref & HRT_KD_LEAF) ? 4u : 1u;
-            if (idx + need > M.n_kd_units) ok = false;
-            return (idx + unit_base) | (ref & HRT_KD_LEAF);
+            return (uint64_t)idx + ((ref & HRT_KD_LEAF) ? 4u : 1u) <= M.n_kd_units;
         };
-        // Walk the tree from the root so that only reachable, well-formed nodelets are accepted.
-        units.resize(unit_base + M.n_kd_units, make_uint4(0, 0, 0, 0));
         if (M.n_leaf_tris) {
-            std::vector<uint32_t> stack{M.kd_root};
-            std::vector<uint8_t> seen(M.n_kd_units, 0);
+            if (M.kd_root == HRT_KD_NIL || !in_range(M.kd_root)) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree");
+            std::vector<uint32_t> new_of(M.n_kd_units, 0xFFFFFFFFu);  // caller's unit index -> unit index in this mesh's new list
+            std::vector<uint32_t> order;                               // caller's refs in the order they are laid out
+            uint32_t cur = 0;
             bool ok = true;
-            { bool o2 = true; (void)rebase(M.kd_root, o2); ok = o2; }
-            while (ok && !stack.empty()) {
-                const uint32_t ref = stack.back();
-                stack.pop_back();
+            auto want = [&](uint32_t ref) {
+                if (ref == HRT_KD_NIL) return;
+                if (!in_range(ref)) { ok = false; return; }
                 const uint32_t idx = ref & ~HRT_KD_LEAF;
-                if (seen[idx]) continue;
-                seen[idx] = 1;
+                if (new_of[idx] != 0xFFFFFFFFu) return;
+                const uint32_t size = (ref & HRT_KD_LEAF) ? 4u : 2u;
+                cur = (cur + size - 1u) & ~(size - 1u);
+                new_of[idx] = cur;
+                cur += size;
+                order.push_back(ref);
+            };
+            auto inner_ok = [&](const hrt_kdunit &u) { return u.w[1] <= 2u && u.w[2] != HRT_KD_NIL && u.w[3] != HRT_KD_NIL && in_range(u.w[2]) && in_range(u.w[3]); };
+            want(M.kd_root);
+            for (size_t q = 0; ok && q < order.size(); ++q) {
+                const uint32_t ref = order[q], idx = ref & ~HRT_KD_LEAF;
                 const hrt_kdunit *u = M.kd_units + idx;
                 if (ref & HRT_KD_LEAF) {
                     if ((uint64_t)u[0].w[3] + u[1].w[3] > M.n_leaf_tris) { ok = false; break; }
                     if (u[1].w[3] >= 0xFFFFu) return fail(HRT_ERR_INVALID, "KD leaf with 65535 or more triangles (the resumable walk keeps a 16-bit leaf cursor): build the tree with a smaller leaf_max");
                     s->max_leaf = std::max(s->max_leaf, u[1].w[3]);
-                    units[unit_base + idx] = make_uint4(u[0].w[0], u[0].w[1], u[0].w[2], u[0].w[3]);
-                    units[unit_base + idx + 1] = make_uint4(u[1].w[0], u[1].w[1], u[1].w[2], u[1].w[3]);
-                    uint32_t r[6];
-                    for (int f = 0; f < 4; ++f) r[f] = rebase(u[2].w[f], ok);
-                    r[4] = rebase(u[3].w[0], ok);
-                    r[5] = rebase(u[3].w[1], ok);
-                    units[unit_base + idx + 2] = make_uint4(r[0], r[1], r[2], r[3]);
-                    units[unit_base + idx + 3] = make_uint4(r[4], r[5], 0, 0);
+                    for (int f = 0; f < 4; ++f) want(u[2].w[f]);
+                    want(u[3].w[0]);
+                    want(u[3].w[1]);
                 } else {
-                    if (u->w[1] > 2u) { ok = false; break; }
-                    const uint32_t l = rebase(u->w[2], ok), r = rebase(u->w[3], ok);
-                    if (u->w[2] == HRT_KD_NIL || u->w[3] == HRT_KD_NIL) { ok = false; break; }
-                    units[unit_base + idx] = make_uint4(u->w[0], u->w[1], l, r);
-                    stack.push_back(u->w[2]);
-                    stack.push_back(u->w[3]);
+                    if (!inner_ok(*u)) { ok = false; break; }
+                    for (int c = 0; c < 2 && ok; ++c) {
+                        const uint32_t child = u->w[2 + c];
+                        if (child & HRT_KD_LEAF) { want(child); continue; }
+                        const hrt_kdunit &y = M.kd_units[child];
+                        if (!inner_ok(y)) { ok = false; break; }
+                        want(y.w[2]);
+                        want(y.w[3]);
+                    }
                 }
             }
             if (!ok) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree");
-            bool o2 = true;
-            dm.root = rebase(M.kd_root, o2);
+            auto tr = [&](uint32_t ref) -> uint32_t { return ref == HRT_KD_NIL ? ref : ((new_of[ref & ~HRT_KD_LEAF] + unit_base) | (ref & HRT_KD_LEAF)); };
+            units.resize(unit_base + ((cur + 3u) & ~3u), make_uint4(0, 0, 0, 0));
+            for (uint32_t ref : order) {
+                const uint32_t idx = ref & ~HRT_KD_LEAF;
+                const hrt_kdunit *u = M.kd_units + idx;
+                uint4 *o = &units[unit_base + new_of[idx]];
+                if (ref & HRT_KD_LEAF) {
+                    o[0] = make_uint4(u[0].w[0], u[0].w[1], u[0].w[2], u[0].w[3]);
+                    o[1] = make_uint4(u[1].w[0], u[1].w[1], u[1].w[2], u[1].w[3]);
+                    o[2] = make_uint4(tr(u[2].w[0]), tr(u[2].w[1]), tr(u[2].w[2]), tr(u[2].w[3]));
+                    o[3] = make_uint4(tr(u[3].w[0]), tr(u[3].w[1]), 0, 0);
+                } else {
+                    uint32_t split[2] = {0, 0}, axis[2] = {3, 3}, exits[4];
+                    for (int c = 0; c < 2; ++c) {
+                        const uint32_t child = u->w[2 + c];
+                        if (child & HRT_KD_LEAF) {
+                            exits[2 * c] = exits[2 * c + 1] = tr(child);
+                        } else {
+                            const hrt_kdunit &y = M.kd_units[child];
+                            split[c] = y.w[0]; axis[c] = y.w[1];
+                            exits[2 * c] = tr(y.w[2]); exits[2 * c + 1] = tr(y.w[3]);
+                        }
+                    }
+                    o[0] = make_uint4(u->w[0], split[0], split[1], u->w[1] | (axis[0] << 2) | (axis[1] << 4));
+                    o[1] = make_uint4(exits[0], exits[1], exits[2], exits[3]);
+                }
+            }
+            dm.root = tr(M.kd_root);
         } else {
             dm.root = HRT_KD_NIL;
         }
@@ -711,7 +749,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     d.n_spheres = D.n_spheres; d.n_quads = D.n_quads; d.n_meshes = D.n_meshes; d.n_lights = D.n_lights;
     d.n_images = D.n_images;
     d.n_kd_units = (uint32_t)units.size();
-    s->lds_units = std::min<uint32_t>(d.n_kd_units, g_rt.lds_budget / 16u);
+    s->lds_units = std::min<uint32_t>(d.n_kd_units, g_rt.lds_budget / 16u) & ~3u;  // whole 64-byte lines: no treelet or leaf straddles
     d.dark_sky = D.dark_sky;
     d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
     HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
@@ -879,11 +917,15 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
         const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_STREAMS * sizeof(SpCtl) + sizeof(SpShared) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4) +
-                               2048u + s->d.tab_rows * 16u;  // + the scene's per-object tables (stream_tables_fit)
+                               2048u + s->d.tab_rows * 16u  // + the scene's per-object tables (stream_tables_fit)
+#ifdef HRT_WALK_SEG
+                               + 2048u  // diagnostic build: 16 accumulators per wave
+#endif
+                               ;
         uint32_t per_cu = (64u * 4u * HRT_SP_MINW) / HRT_SP_WG;  // workgroups resident per CU (HRT_SP_MINW waves per SIMD in all) ...
         while (per_cu > 1u && 160u * 1024u / per_cu < fixed + 16u * 1024u) --per_cu;  // ... as far as the LDS pools allow
         const uint32_t room = (160u * 1024u / per_cu - fixed) / 16u;
-        if (!(flags & HRT_FLAG_NO_LDS_TREE)) R.lds_units = std::min<uint32_t>(s->d.n_kd_units, room);
+        if (!(flags & HRT_FLAG_NO_LDS_TREE)) R.lds_units = std::min<uint32_t>(s->d.n_kd_units, room) & ~3u;  // whole 64-byte lines: no treelet or leaf straddles
         lds_bytes = fixed + R.lds_units * 16u;
         grid = std::min<uint32_t>((uint32_t)g_rt.cus * per_cu, R.tiles_owned);
         {   // tiles per work unit: as many as keep one unit (tiles x 64 pixels x samples per fold) within HRT_SP_UNIT paths
@@ -918,7 +960,7 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
             // 4 workgroups per CU: 160 KiB = 4 x (27 KiB of backed-up streams + 12 KiB of nodelets)
             const uint32_t wgs = 1024u / HRT_WG, backup = HRT_DS_FIELDS * HRT_WG * 4u;
             const uint32_t room = (156u * 1024u / wgs - backup) / 16u;
-            if (R.lds_units > room) R.lds_units = room;
+            if (R.lds_units > room) R.lds_units = room & ~3u;
             lds_bytes = R.lds_units * 16u + backup;
             kfn = s->d.n_lights ? (const void *)hrt_trace2_kernel_lights : (const void *)hrt_trace2_kernel;
         }

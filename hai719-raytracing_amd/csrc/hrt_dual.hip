@@ -30,10 +30,10 @@
 #define HRT_DS_TRIPS 8     // KD-walk trips per stage B visit; an unfinished walk resumes at the next visit
 #endif
 #ifndef HRT_WALK_LEVELS
-#define HRT_WALK_LEVELS 3  // inner nodes descended per trip (A/B on MI355X, Cornell+mesh / mesh_in_box: 1 -> 48.3 / 59.8 ms, 2 -> 44.2 / 54.6, 3 -> 43.5 / 53.0, 4 -> 43.6 / 52.7)
+#define HRT_WALK_LEVELS 2  // treelets (two levels each) descended per trip; with single 16-byte nodes, levels per trip on Cornell+mesh / mesh_in_box: 1 -> 48.3 / 59.8 ms, 2 -> 44.2 / 54.6, 3 -> 43.5 / 53.0, 4 -> 43.6 / 52.7
 #endif
 #ifndef HRT_WALK_ROPES
-#define HRT_WALK_ROPES 0   // 1: request the rope nodelets together with the leaf header
+#define HRT_WALK_ROPES 1   // 1: request the rope nodelets together with the leaf header (one round trip less per cell; 1080p@64 ms Cornell+mesh / mesh_in_box / pool: 0 -> 54.4 / 61.8 / 109.2, 1 -> 53.9 / 61.0 / 107.2)
 #endif
 #define HRT_DS_FIELDS 34   // dwords of one backed-up stream
 #define HRT_DS_NONE 0xFFFFFFFFu
@@ -123,8 +123,22 @@ __device__ __forceinline__ void ds_fresh(PathState &p, bool live) {
 
 // Up to `trips` trips of the walk of mesh M (mesh_traverse's loop body, KDTree.cpp:31-85 semantics);
 // true when the walk is complete: w.best_* then hold the mesh's closest triangle with t >= 0, if any.
+#ifdef HRT_WALK_SEG  // diagnostic: every stamp drains the wave's memory counters first, so the segments are serialised.  cx.st points at
+                     // 16 u64 accumulators of THIS wave in LDS (hrt_stream.hip); the first active lane adds the wave's clocks
+typedef unsigned long long __attribute__((address_space(3))) *lu64;
+#define WSEG_ADD(k, v) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) ((lu64)(uint32_t)(uintptr_t)cx.st)[k] += (unsigned long long)(v); } while (0)
+#define WSEG_START() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long wseg_last = __builtin_readcyclecounter()
+#define WSEG(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                     WSEG_ADD(k, t_ - wseg_last); wseg_last = t_; } while (0)
+#define WCOUNT(k, v) WSEG_ADD(k, v)
+#else
+#define WSEG_START() do { } while (0)
+#define WSEG(k) do { } while (0)
+#define WCOUNT(k, v) do { } while (0)
+#endif
 template <class CX, class MP>  // cmesh: wave-uniform mesh, scalar record loads; gmesh: every lane its own mesh, vector loads
 __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3 inv, Walk &w, int trips) {
+    WSEG_START();
     if (w.ref == HRT_KD_NIL) {  // start: clip the ray to the root cell
         float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
         float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
@@ -138,6 +152,7 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
         if (!(t_entry <= t_scene_exit)) return true;
         w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
     }
+    WSEG(4);  // start of a walk: root clip, irregular triangles
     gu4 g_units = (gu4)cx.S->kd_units;
     const Soup sp = soup_of(cx.S);
     const uint32_t tri_base = M->tri_base;
@@ -145,29 +160,30 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
     float t_entry = w.t_entry;
     f3 p = ray.o + t_entry * ray.d;
     for (int trip = 0; trip < trips && ref != HRT_KD_NIL; ++trip) {
+        WCOUNT(8, 1); WCOUNT(11, __popcll(__ballot(true)));
 #pragma unroll
-        for (int lvl = 0; lvl < HRT_WALK_LEVELS; ++lvl) {
-            if (!(ref & HRT_KD_LEAF)) {
-                const uint4 nd = kd_fetch(g_units, cx, ref);
-                const float split = __uint_as_float(nd.x);
-                const float pc = comp(p, nd.y), dc = comp(ray.d, nd.y);
-                const bool left = (pc < split) || (pc == split && dc < 0.f);
-                ref = left ? nd.z : nd.w;
-            }
-        }
+        for (int lvl = 0; lvl < HRT_WALK_LEVELS; ++lvl)
+            if (!(ref & HRT_KD_LEAF)) ref = kd_descend(g_units, cx, ref, p, ray.d);  // two levels each
+        WSEG(0);  // descent
         if (ref & HRT_KD_LEAF) {
+            WCOUNT(9, 1); WCOUNT(5, __popcll(__ballot(true)));
             const uint32_t lu = ref & ~HRT_KD_LEAF;
-            const uint4 l0 = kd_fetch(g_units, cx, lu);
-            const uint4 l1 = kd_fetch(g_units, cx, lu + 1);
 #if HRT_WALK_ROPES
-            const uint4 rp0 = kd_fetch(g_units, cx, lu + 2), rp1 = kd_fetch(g_units, cx, lu + 3);
+            uint4 l0, l1, rp0, rp1;
+            kd_fetch4(g_units, cx, lu, l0, l1, rp0, rp1);
+#else
+            uint4 l0, l1;
+            kd_fetch2(g_units, cx, lu, l0, l1);
 #endif
             const uint32_t first = tri_base + l0.w, cnt = l1.w;
+            WSEG(1);  // leaf nodelets
             if (k == 0xFFFFu) k = 0;
             if (k < cnt) {
+                WCOUNT(10, 1); WCOUNT(6, __popcll(__ballot(true)));
                 bool found_ = false;
                 k = tri_test_run(sp, first, cnt, k, ray, w.best_t, w.best_tri, w.bu, w.bv, found_);
             }
+            WSEG(2);  // triangles
             if (k >= cnt) {  // leave the cell through its exit face
                 const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
                 const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
@@ -193,6 +209,7 @@ __device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3
                     if (++count >= HRT_WALK_CELLS) ref = HRT_KD_NIL;  // mesh_traverse's bound on the cells of one walk
                 }
             }
+            WSEG(3);  // exit face, rope
         }
     }
     w.ref = ref; w.t_entry = t_entry; w.kk = (count << 16) | k;

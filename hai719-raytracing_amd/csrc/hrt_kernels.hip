@@ -312,13 +312,49 @@ __device__ __forceinline__ bool mesh_gate_box(const B &box, const Ray &ray, f3 i
 template <bool EXACT>
 __device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) { return mesh_gate_box<EXACT>(MeshBox{M}, ray, inv); }
 
-// Nodelet fetch: the leading `lds_n` units of the kd array are resident in LDS.
+// Nodelet fetch: the leading `lds_n` units of the kd array (a multiple of 4: treelets and leaves never straddle) are resident in
+// LDS.  A wave's lanes can sit on both sides, so both paths run -- the LDS one FIRST and all units of a treelet / leaf under ONE
+// pair of branches: the global loads then overwrite registers whose LDS read has long landed (a cheap lgkmcnt wait) and are all
+// in flight together.  (With one if / else per unit hipcc put the global load first and had to wait for it before the LDS read
+// could write the same registers: a leaf's four units cost four memory round trips in a row.)
 template <class CX>
 __device__ __forceinline__ uint4 kd_fetch(gu4 g, const CX &cx, uint32_t i) {
-    uint4 r;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
     if (i < cx.lds_n) r = ld(cx.lds, i);
-    else r = ld(g, i);
+    if (i >= cx.lds_n) r = ld(g, i);
     return r;
+}
+template <class CX>
+__device__ __forceinline__ void kd_fetch2(gu4 g, const CX &cx, uint32_t i, uint4 &a, uint4 &b) {
+    a = b = make_uint4(0u, 0u, 0u, 0u);
+    if (i < cx.lds_n) { a = ld(cx.lds, i); b = ld(cx.lds, i + 1u); }
+    if (i >= cx.lds_n) { a = ld(g, i); b = ld(g, i + 1u); }
+}
+template <class CX>
+__device__ __forceinline__ void kd_fetch4(gu4 g, const CX &cx, uint32_t i, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+    a = b = c = d = make_uint4(0u, 0u, 0u, 0u);
+    if (i < cx.lds_n) { a = ld(cx.lds, i); b = ld(cx.lds, i + 1u); c = ld(cx.lds, i + 2u); d = ld(cx.lds, i + 3u); }
+    if (i >= cx.lds_n) { a = ld(g, i); b = ld(g, i + 1u); c = ld(g, i + 2u); d = ld(g, i + 3u); }
+}
+
+// Inner nodes of the device's tree are TREELETS of two levels in 32 bytes (hrt_api.hip scene_create_impl builds them from the
+// caller's 16-byte nodelets): {split, split of the left child, split of the right child, axes} {the four grandchildren's refs},
+// axes = 2 bits per node, 3 = "no such node: the child is a leaf, take the first exit of its pair".  One round trip (two
+// 16-byte loads of one half line) descends two levels; the per-node rule is KDTree.cpp's: left when the point lies below the
+// split, or on it with the ray heading down.
+template <class CX>
+__device__ __forceinline__ uint32_t kd_descend(gu4 g, const CX &cx, uint32_t ref, f3 p, f3 d) {
+    uint4 a, b;
+    kd_fetch2(g, cx, ref, a, b);
+    const uint32_t ax0 = a.w & 3u;
+    const float s0 = __uint_as_float(a.x);
+    const float pc0 = comp(p, ax0), dc0 = comp(d, ax0);
+    const bool left0 = (pc0 < s0) || (pc0 == s0 && dc0 < 0.f);
+    const uint32_t ax1 = (left0 ? a.w >> 2 : a.w >> 4) & 3u;
+    const float s1 = __uint_as_float(left0 ? a.y : a.z);
+    const float pc1 = comp(p, ax1), dc1 = comp(d, ax1);
+    const bool left1 = ax1 == 3u || (pc1 < s1) || (pc1 == s1 && dc1 < 0.f);
+    return left0 ? (left1 ? b.x : b.y) : (left1 ? b.z : b.w);
 }
 
 // One triangle of the soup against the ray: Triangle::getIntersection (Triangle.h:77-126) with the constructor's and
@@ -333,19 +369,27 @@ struct Soup {
     gf4 planes, rows;
 };
 __device__ __forceinline__ Soup soup_of(cscene S) { return Soup{(gf4)S->tri_planes, (gf4)S->tris}; }
-__device__ __forceinline__ bool tri_test_plane(gf4 tr, const float4 pl, const Ray &ray, float &best_t, float &bu, float &bv) {
+// In two halves, so that a batch can request the rows of all its candidates together: tri_plane_t is :80-96 (false: the ray does
+// not reach the triangle's plane in front of it and closer than the best so far), tri_inside the rest.
+__device__ __forceinline__ bool tri_plane_t(const float4 pl, const Ray &ray, float best_t, float &t) {
     const f3 n = mk(pl);
     const float dotRN = dot(ray.d, n);
     if (!(dotRN < 0.f)) return false;                     // :80-91 parallel / back-facing (NaN: no hit)
-    const float t = (pl.w - dot(ray.o, n)) / dotRN;       // :95
-    if (t < 0.f || !(t < best_t)) return false;           // :96, then KDTree.cpp:44
-    const float4 r0 = ld(tr, 0), r1 = ld(tr, 1), r2 = ld(tr, 2), r4 = ld(tr, 3);
+    t = (pl.w - dot(ray.o, n)) / dotRN;                   // :95
+    return !(t < 0.f || !(t < best_t));                   // :96, then KDTree.cpp:44
+}
+__device__ __forceinline__ bool tri_inside(const float4 r0, const float4 r1, const float4 r2, const float4 r4, const Ray &ray, float t, float &u1, float &u2) {
     const f3 v2 = (ray.o + t * ray.d) - mk(r0);
     const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
-    const float u1 = (r4.x * d20 - r2.w * d21) / r4.y;    // :72-74
-    const float u2 = (r1.w * d21 - r2.w * d20) / r4.y;
+    u1 = (r4.x * d20 - r2.w * d21) / r4.y;                // :72-74
+    u2 = (r1.w * d21 - r2.w * d20) / r4.y;
     const float u0 = 1 - u1 - u2;
-    if (!(u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1)) return false;
+    return u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1;
+}
+__device__ __forceinline__ bool tri_test_plane(gf4 tr, const float4 pl, const Ray &ray, float &best_t, float &bu, float &bv) {
+    float t, u1, u2;
+    if (!tri_plane_t(pl, ray, best_t, t)) return false;
+    if (!tri_inside(ld(tr, 0), ld(tr, 1), ld(tr, 2), ld(tr, 3), ray, t, u1, u2)) return false;
     best_t = t; bu = u1; bv = u2;
     return true;
 }
@@ -353,7 +397,8 @@ __device__ __forceinline__ bool tri_test(const Soup &sp, uint32_t slot, const Ra
     return tri_test_plane(sp.rows + HRT_TRI_ROWS * slot, ld(sp.planes, slot), ray, best_t, bu, bv);
 }
 // Triangles [k, min(k + HRT_LEAF_BATCH, cnt)) of the run that starts at soup slot `first`, in order; returns the new k.
-// Requires k < cnt.
+// Requires k < cnt.  (Requesting the rows of every candidate of the batch together, before finishing them in order, saves a
+// round trip when two planes are reached -- and cost 22 more spilled VGPRs: 1-2 % slower on MI355X, dropped.)
 __device__ __forceinline__ uint32_t tri_test_run(const Soup &sp, uint32_t first, uint32_t cnt, uint32_t k, const Ray &ray, float &best_t,
                                                  uint32_t &best_tri, float &bu, float &bv, bool &found) {
     float4 pl[HRT_LEAF_BATCH];
@@ -461,20 +506,11 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
 #endif                       // stops a walk that rounding sends back and forth between two cells.  Triangle tests are NOT counted:
                              // a leaf of any size is tested to its end (smaller values: ablation only, not parity-safe)
     for (uint32_t cells = 0; cells < HRT_WALK_CELLS && ref != HRT_KD_NIL;) {  // bounded: every wave leaves
-#pragma unroll
-        for (int lvl = 0; lvl < 2; ++lvl) {
-            if (!(ref & HRT_KD_LEAF)) {
-                const uint4 nd = kd_fetch(g_units, cx, ref);
-                const float split = __uint_as_float(nd.x);
-                const float pc = comp(p, nd.y), dc = comp(ray.d, nd.y);
-                const bool left = (pc < split) || (pc == split && dc < 0.f);
-                ref = left ? nd.z : nd.w;
-            }
-        }
+        if (!(ref & HRT_KD_LEAF)) ref = kd_descend(g_units, cx, ref, p, ray.d);  // two levels
         if (ref & HRT_KD_LEAF) {
             const uint32_t lu = ref & ~HRT_KD_LEAF;
-            const uint4 l0 = kd_fetch(g_units, cx, lu);
-            const uint4 l1 = kd_fetch(g_units, cx, lu + 1);
+            uint4 l0, l1;
+            kd_fetch2(g_units, cx, lu, l0, l1);
             if (cnt == ~0u) { first = tri_base + l0.w; cnt = l1.w; k = 0; }
 #ifdef HRT_ABL_NO_TRI  // ablation only
             k = cnt;
@@ -896,14 +932,32 @@ __device__ __forceinline__ Surface shade(const CX &cx, const Ray &ray, const Hit
         const uint32_t tex_type = __float_as_uint(m1.z);
         const bool emissive = __float_as_uint(m1.w) != 0u;
         sf.n = mk(ld(q, 1));
-        sf.albedo = mat_texture(S, cx.lut, m, tex_type, mk(m0), h.a0, h.a1);
-        const int nmap = (int)__float_as_uint(ld(m, 5).y);
+        // The colour texel and the normal-map texel are REQUESTED TOGETHER (two masked loads, nothing between them that needs
+        // either), then used: mat_texture() followed by the normal-map branch made them two memory round trips in a row on
+        // every textured, normal-mapped wall.  Same expressions, same values.
+        const float4 m2 = ld(m, 2), m3 = ld(m, 3), m5 = ld(m, 5);
+        const int nmap = (int)__float_as_uint(m5.y);
+        bool image = false;
+        uint32_t px_c = 0u, px_n = 0u;
+        if (tex_type == 2u) {
+            const float4 geo = ld(m, 6);
+            image = !((int)__float_as_uint(m5.x) < 0 || (int)__float_as_uint(geo.y) < 1 || (int)__float_as_uint(geo.z) < 1);
+            if (image) px_c = texel(S, geo, h.a0, h.a1, m2.w, m3.w);
+        }
+        if (nmap >= 0) px_n = texel(S, ld(m, 7), h.a0, h.a1, m2.w, m3.w);
+        f3 tex = mk(m0);  // Material::texture, Material.cpp:62-112 (mat_texture above, with the texel already on its way)
+        if (tex_type == 1u) tex = ((int)(h.a0 * m2.w) % 2 == (int)(h.a1 * m3.w) % 2) ? mk(m2) : mk(m3);
+        else if (tex_type == 2u)
+            tex = image ? unit_rgb(cx.lut, px_c) : (((int)((double)h.a0 * 8.) % 2 == (int)((double)h.a1 * 8.) % 2) ? mk(0.f, 0.f, 0.f) : mk(1.f, 0.f, 1.f));
+        sf.albedo = tex;
         if (nmap >= 0) {  // Material::get_normal, Material.cpp:114-130
-            const uint32_t px = texel(S, ld(m, 7), h.a0, h.a1, ld(m, 2).w, ld(m, 3).w);
-            const float nx = cx.lut[256u + (px & 255u)], ny = cx.lut[256u + ((px >> 8) & 255u)], nz = cx.lut[256u + ((px >> 16) & 255u)];
+            const float nx = cx.lut[256u + (px_n & 255u)], ny = cx.lut[256u + ((px_n >> 8) & 255u)], nz = cx.lut[256u + ((px_n >> 16) & 255u)];
             sf.n = normalize(nx * mk(ld(q, 5)) + ny * mk(ld(q, 6)) + nz * sf.n);
         }
-        sf.emission = mat_emit(S, cx.lut, m, tex_type, emissive, h.a0, h.a1);
+        if (emissive) {  // mat_emit: the light colour, or the texture value at the same (u, v) -- the texel fetched above -- times the intensity
+            const float4 lc = ld(m, 4);
+            sf.emission = (tex_type == 0u ? mk(lc) : (tex_type <= 2u ? tex : mk(0.f, 0.f, 0.f))) * lc.w;
+        }
     } else {
         const typename CX::tabmesh M = cx.tmesh + h.index;  // per-lane mesh record
         mat_id = M->material;

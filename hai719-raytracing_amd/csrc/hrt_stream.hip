@@ -221,6 +221,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     cx.flags = R.flags;
     unsigned long long stamps_local[17];
     cx.st = stamps_local;
+#ifdef HRT_WALK_SEG  // 16 u64 accumulators per wave behind the nodelets (hrt_api.hip reserves the 2 KB)
+    {
+        unsigned long long *wseg = reinterpret_cast<unsigned long long *>(s_units + R.lds_units) + (threadIdx.x >> 6) * 16u;
+        if ((threadIdx.x & 63u) < 16u) wseg[threadIdx.x & 63u] = 0ull;
+        cx.st = wseg;
+    }
+#endif
     ccam cam = (ccam)R.cam;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     {
@@ -648,6 +655,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #ifdef HRT_SP_SEG
     if (lane == 0 && R.stamps)
         for (int k = 0; k < 8; ++k) atomicAdd(R.stamps + k, seg[k]);
+#endif
+#ifdef HRT_WALK_SEG  // diagnostic build: where the trips of the KD walk spend their clocks (hrt_dual.hip mesh_walk)
+    if (lane == 0 && R.stamps)
+        for (int k = 0; k < 12; ++k) atomicAdd(R.stamps + k, cx.st[k]);
 #endif
 #ifdef HRT_SP_DEBUG
     if (lane == 0 && R.stamps) {  // per-wave sums: [0] clocks in chunk loops, [1] clocks alive, [2] cycles, [3] chunks, [4] clocks in the serial section
