@@ -313,10 +313,11 @@ template <bool EXACT>
 __device__ __forceinline__ bool mesh_gate(cmesh M, const Ray &ray, f3 inv) { return mesh_gate_box<EXACT>(MeshBox{M}, ray, inv); }
 
 // Nodelet fetch: the leading `lds_n` units of the kd array (a multiple of 4: treelets and leaves never straddle) are resident in
-// LDS.  A wave's lanes can sit on both sides, so both paths run -- the LDS one FIRST and all units of a treelet / leaf under ONE
-// pair of branches: the global loads then overwrite registers whose LDS read has long landed (a cheap lgkmcnt wait) and are all
-// in flight together.  (With one if / else per unit hipcc put the global load first and had to wait for it before the LDS read
-// could write the same registers: a leaf's four units cost four memory round trips in a row.)
+// LDS.  A wave's lanes can sit on both sides, so both paths run, and the second one writes the registers of the first: hipcc
+// drains the first path's loads before it issues the second's.  Hence ALL units of a treelet / leaf go under ONE pair of
+// branches -- their global loads are in flight together and the drain costs one round trip.  (With one if / else per unit a
+// leaf's four units cost four memory round trips in a row: 1080p@64 pool 113.9 -> 109.2 ms, mesh_in_box 63.8 -> 61.8.  Forcing
+// the LDS path first with a compiler barrier, so that only the short LDS latency is drained, measured no better.)
 template <class CX>
 __device__ __forceinline__ uint4 kd_fetch(gu4 g, const CX &cx, uint32_t i) {
     uint4 r = make_uint4(0u, 0u, 0u, 0u);

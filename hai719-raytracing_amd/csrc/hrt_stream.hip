@@ -135,6 +135,41 @@ struct SpRef {             // one dword of a path record
 };
 __device__ __forceinline__ SpRef<float> spf(const SpLds &L, int field, uint32_t slot) { return SpRef<float>{reinterpret_cast<float *>(L.st) + SP_AT(field, slot)}; }
 __device__ __forceinline__ SpRef<uint32_t> spu(const SpLds &L, int field, uint32_t slot) { return SpRef<uint32_t>{L.st + SP_AT(field, slot)}; }
+// A path record is read and written in its eight aligned 16-byte GROUPS (one vector memory instruction each):
+//   g0 {o.xyz, d.x}  g1 {d.y, d.z, hit t, hit kind|index}  g2 {hit a0, a1, triangle, meshes still to walk}
+//   g3 {walk ref, t_entry, cursor, best t}  g4 {best triangle, bu, bv, -}  g5 {time, RNG key k0, k1, path number}
+//   g6 {throughput.rgb, radiance.r}  g7 {radiance.g, .b, RNG position, bounces left}
+// (Left to the load / store vectoriser, the per-field accesses of a hit visit became 11 loads -- three of them issued late,
+// behind the first waits -- and 7 stores of mixed widths; by group they are 6 and 5.)
+__device__ __forceinline__ uint4 sp_ld4(const SpLds &L, int g, uint32_t slot) {
+#if HRT_SP_GLOBAL
+    const uint4 *p = reinterpret_cast<const uint4 *>(L.st + SP_AT(4 * g, slot));
+    return *p;
+#else
+    return make_uint4(L.st[SP_AT(4 * g, slot)], L.st[SP_AT(4 * g + 1, slot)], L.st[SP_AT(4 * g + 2, slot)], L.st[SP_AT(4 * g + 3, slot)]);
+#endif
+}
+__device__ __forceinline__ void sp_st4(const SpLds &L, int g, uint32_t slot, uint4 v) {
+#if HRT_SP_GLOBAL
+    uint4 *p = reinterpret_cast<uint4 *>(L.st + SP_AT(4 * g, slot));
+    *p = v;
+#else
+    L.st[SP_AT(4 * g, slot)] = v.x; L.st[SP_AT(4 * g + 1, slot)] = v.y; L.st[SP_AT(4 * g + 2, slot)] = v.z; L.st[SP_AT(4 * g + 3, slot)] = v.w;
+#endif
+}
+__device__ __forceinline__ uint4 sp_pack(float a, float b, float c, float d) { return make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)); }
+__device__ __forceinline__ void sp_unpack_ray_hit(const uint4 g0, const uint4 g1, const uint4 g2, Ray &ray, Hit &h, uint32_t &pm) {
+    ray.o = mk(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z));
+    ray.d = mk(__uint_as_float(g0.w), __uint_as_float(g1.x), __uint_as_float(g1.y));
+    h.t = __uint_as_float(g1.z); h.kind = g1.w >> 28; h.index = g1.w & 0x0FFFFFFFu;
+    h.a0 = __uint_as_float(g2.x); h.a1 = __uint_as_float(g2.y); h.tri = g2.z; pm = g2.w;
+}
+// g0, g1, g2 of a ray with its closest hit so far
+__device__ __forceinline__ void sp_store_ray_hit(const SpLds &L, uint32_t slot, const Ray &ray, const Hit &h, uint32_t pm) {
+    sp_st4(L, 0, slot, sp_pack(ray.o.x, ray.o.y, ray.o.z, ray.d.x));
+    sp_st4(L, 1, slot, make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(h.t), (h.kind << 28) | h.index));
+    sp_st4(L, 2, slot, make_uint4(__float_as_uint(h.a0), __float_as_uint(h.a1), h.tri, pm));
+}
 __device__ __forceinline__ uint16_t *spq(const SpLds &L, int which, uint32_t parity) { return L.q + (2 * which + parity) * HRT_SP_QCAP; }
 
 // Wave-aggregated append of `slot` for the lanes with `want`: __ballot + one LDS atomic by the leader.
@@ -446,14 +481,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         SEG_START(HRT_SP_SEG_KIND == 2);
                         if (act) {
                             slot = qTi[e] & (HRT_SP_POOL - 1u);
-                            ray = sp_load_ray(L, slot);
-                            h = sp_load_hit(L, slot);
-                            pm = spu(L, SP_PM, slot);
+                            const uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g3 = sp_ld4(L, 3, slot),
+                                        g4 = sp_ld4(L, 4, slot);
+                            sp_unpack_ray_hit(g0, g1, g2, ray, h, pm);  // (the mesh walk does not read ray.time)
                             pm_before = pm;
-                            w.ref = spu(L, SP_WREF, slot); w.t_entry = spf(L, SP_WTE, slot); w.kk = spu(L, SP_WKK, slot);
+                            w.ref = g3.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
                             ref_in = w.ref;
-                            w.best_t = spf(L, SP_WBT, slot); w.best_tri = spu(L, SP_WTRI, slot); w.bu = spf(L, SP_WBU, slot);
-                            w.bv = spf(L, SP_WBV, slot);
+                            w.best_tri = g4.x; w.bu = __uint_as_float(g4.y); w.bv = __uint_as_float(g4.z);
                         }
 #ifdef HRT_SP_SEG
                         asm volatile("" : "+v"(ray.o.x), "+v"(w.t_entry), "+v"(h.t));
@@ -465,11 +499,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         SEG(1);  // T: walk
                         if (act) {
                             const uint32_t pm_in = pm_before;
-                            if (pm != pm_in) sp_store_hit(L, slot, h, pm);  // a mesh was finished: the best hit may have changed
+                            if (pm != pm_in) {  // a mesh was finished: the best hit may have changed (g1 also carries d.y, d.z: rewritten as read)
+                                sp_st4(L, 1, slot, make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(h.t), (h.kind << 28) | h.index));
+                                sp_st4(L, 2, slot, make_uint4(__float_as_uint(h.a0), __float_as_uint(h.a1), h.tri, pm));
+                            }
                             if (!walked) {  // the state of the walk in progress
-                                spu(L, SP_WREF, slot) = w.ref; spf(L, SP_WTE, slot) = w.t_entry; spu(L, SP_WKK, slot) = w.kk;
-                                spf(L, SP_WBT, slot) = w.best_t; spu(L, SP_WTRI, slot) = w.best_tri; spf(L, SP_WBU, slot) = w.bu;
-                                spf(L, SP_WBV, slot) = w.bv;
+                                sp_st4(L, 3, slot, make_uint4(w.ref, __float_as_uint(w.t_entry), w.kk, __float_as_uint(w.best_t)));
+                                sp_st4(L, 4, slot, make_uint4(w.best_tri, __float_as_uint(w.bu), __float_as_uint(w.bv), 0u));
                             } else if (ref_in != HRT_KD_NIL) {
                                 spu(L, SP_WREF, slot) = HRT_KD_NIL;  // invariant: SP_WREF is NIL whenever the path is not in a T queue
                             }
@@ -509,11 +545,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 const float v = ((float)py + rng.next()) / (float)R.h;
                                 const float tm = rng.next();
                                 ray = camera_ray<EXACT>(cam, u, v, tm);
-                                spf(L, SP_TM, slot) = tm;
-                                spf(L, SP_TR, slot) = 1.f; spf(L, SP_TG, slot) = 1.f; spf(L, SP_TB, slot) = 1.f;
-                                spf(L, SP_RR, slot) = 0.f; spf(L, SP_RG, slot) = 0.f; spf(L, SP_RB, slot) = 0.f;
-                                spu(L, SP_K0, slot) = rng.k0; spu(L, SP_K1, slot) = rng.k1; spu(L, SP_RI, slot) = rng.i;
-                                spu(L, SP_N, slot) = n; spu(L, SP_REM, slot) = 6u;  // MAXBOUNCES
+                                sp_st4(L, 5, slot, make_uint4(__float_as_uint(tm), rng.k0, rng.k1, n));
+                                sp_st4(L, 6, slot, sp_pack(1.f, 1.f, 1.f, 0.f));                                  // throughput 1, radiance 0
+                                sp_st4(L, 7, slot, make_uint4(0u, 0u, rng.i, 6u));                               // MAXBOUNCES
                                 trace = true;
                             } else {  // pixel outside a ragged image: the sample is zero, the slot stays free
                                 float *o = scratch + (size_t)n * 3u;
@@ -522,11 +556,15 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             }
                         } else if (act) {
                             slot = qHi[from_back ? (uint32_t)HRT_SP_QCAP - 1u - e : e] & (HRT_SP_POOL - 1u);
-                            ray = sp_load_ray(L, slot);
-                            const Hit h = sp_load_hit(L, slot);
-                            f3 thr = mk(spf(L, SP_TR, slot), spf(L, SP_TG, slot), spf(L, SP_TB, slot));
-                            f3 rad = mk(spf(L, SP_RR, slot), spf(L, SP_RG, slot), spf(L, SP_RB, slot));
-                            int remaining = (int)spu(L, SP_REM, slot);
+                            const uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g5 = sp_ld4(L, 5, slot),
+                                        g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
+                            Hit h;
+                            uint32_t pm_unused;
+                            sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
+                            ray.time = __uint_as_float(g5.x);
+                            f3 thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
+                            f3 rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
+                            int remaining = (int)g7.w;
 #ifdef HRT_SP_SEG
                             asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
 #endif
@@ -537,7 +575,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 ended = true;
                             } else {
                                 Rng rng;
-                                rng.k0 = spu(L, SP_K0, slot); rng.k1 = spu(L, SP_K1, slot); rng.i = spu(L, SP_RI, slot);
+                                rng.k0 = g5.y; rng.k1 = g5.z; rng.i = g7.z;
                                 const Surface sf = shade(cx, ray, h);
                                 SEG(1);  // shade: material rows, texel, normal map
                                 f3 direct = mk(0.f, 0.f, 0.f);
@@ -549,15 +587,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                 --remaining;
                                 ended = (remaining == 0);
                                 if (!ended) {
-                                    spf(L, SP_TR, slot) = thr.x; spf(L, SP_TG, slot) = thr.y; spf(L, SP_TB, slot) = thr.z;
-                                    spf(L, SP_RR, slot) = rad.x; spf(L, SP_RG, slot) = rad.y; spf(L, SP_RB, slot) = rad.z;
-                                    spu(L, SP_RI, slot) = rng.i;
-                                    spu(L, SP_REM, slot) = (uint32_t)remaining;
+                                    sp_st4(L, 6, slot, sp_pack(thr.x, thr.y, thr.z, rad.x));
+                                    sp_st4(L, 7, slot, make_uint4(__float_as_uint(rad.y), __float_as_uint(rad.z), rng.i, (uint32_t)remaining));
                                     trace = true;
                                 }
                             }
                             if (ended) {  // Scene.h:348: the sample's colour, parked until the ordered fold
-                                const uint32_t n = min((uint32_t)spu(L, SP_N, slot), (uint32_t)HRT_SP_UNIT - 1u);  // stays inside the scratch
+                                const uint32_t n = min(g5.w, (uint32_t)HRT_SP_UNIT - 1u);  // the path's number; stays inside the scratch
                                 float *o = scratch + (size_t)n * 3u;
                                 o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
                                 freed = true;
@@ -576,8 +612,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             SEG(5);  // mesh gates
                         }
                         if (trace) {
-                            sp_store_ray(L, slot, ray);
-                            sp_store_hit(L, slot, hn, pmn);
+                            sp_store_ray_hit(L, slot, ray, hn, pmn);
                             if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
                             to_mesh = pmn != 0u;
                             kind = hn.kind;
