@@ -143,20 +143,24 @@ __device__ __forceinline__ SpRef<uint32_t> spu(const SpLds &L, int field, uint32
 // behind the first waits -- and 7 stores of mixed widths; by group they are 6 and 5.)
 __device__ __forceinline__ uint4 sp_ld4(const SpLds &L, int g, uint32_t slot) {
 #if HRT_SP_GLOBAL
-    const uint4 *p = reinterpret_cast<const uint4 *>(L.st + SP_AT(4 * g, slot));
-    return *p;
+    // a NATIVE vector in the global address space; the caller pins the groups of a visit together (SP_PIN) once all are
+    // requested: hipcc otherwise takes them apart, drops and sinks components and re-merges the rest across group boundaries
+    const v4u v = ((gu4)(L.st + SP_AT(4 * g, slot)))[0];
+    return make_uint4(v.x, v.y, v.z, v.w);
 #else
     return make_uint4(L.st[SP_AT(4 * g, slot)], L.st[SP_AT(4 * g + 1, slot)], L.st[SP_AT(4 * g + 2, slot)], L.st[SP_AT(4 * g + 3, slot)]);
 #endif
 }
 __device__ __forceinline__ void sp_st4(const SpLds &L, int g, uint32_t slot, uint4 v) {
 #if HRT_SP_GLOBAL
-    uint4 *p = reinterpret_cast<uint4 *>(L.st + SP_AT(4 * g, slot));
-    *p = v;
+    v4u w;
+    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    *((v4u __attribute__((address_space(1))) *)(L.st + SP_AT(4 * g, slot))) = w;
 #else
     L.st[SP_AT(4 * g, slot)] = v.x; L.st[SP_AT(4 * g + 1, slot)] = v.y; L.st[SP_AT(4 * g + 2, slot)] = v.z; L.st[SP_AT(4 * g + 3, slot)] = v.w;
 #endif
 }
+#define SP_PIN1(g) "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w)
 __device__ __forceinline__ uint4 sp_pack(float a, float b, float c, float d) { return make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)); }
 __device__ __forceinline__ void sp_unpack_ray_hit(const uint4 g0, const uint4 g1, const uint4 g2, Ray &ray, Hit &h, uint32_t &pm) {
     ray.o = mk(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z));
@@ -481,8 +485,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         SEG_START(HRT_SP_SEG_KIND == 2);
                         if (act) {
                             slot = qTi[e] & (HRT_SP_POOL - 1u);
-                            const uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g3 = sp_ld4(L, 3, slot),
-                                        g4 = sp_ld4(L, 4, slot);
+                            uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g3 = sp_ld4(L, 3, slot),
+                                  g4 = sp_ld4(L, 4, slot);
+#if HRT_SP_GLOBAL
+                            asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g3), SP_PIN1(g4));
+#endif
                             sp_unpack_ray_hit(g0, g1, g2, ray, h, pm);  // (the mesh walk does not read ray.time)
                             pm_before = pm;
                             w.ref = g3.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
@@ -556,8 +563,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             }
                         } else if (act) {
                             slot = qHi[from_back ? (uint32_t)HRT_SP_QCAP - 1u - e : e] & (HRT_SP_POOL - 1u);
-                            const uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g5 = sp_ld4(L, 5, slot),
-                                        g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
+                            uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g5 = sp_ld4(L, 5, slot),
+                                  g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
+#if HRT_SP_GLOBAL
+                            asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g5), SP_PIN1(g6), SP_PIN1(g7));
+#endif
                             Hit h;
                             uint32_t pm_unused;
                             sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
