@@ -126,7 +126,7 @@ __device__ __forceinline__ void ds_fresh(PathState &p, bool live) {
 #ifdef HRT_WALK_SEG  // diagnostic: every stamp drains the wave's memory counters first, so the segments are serialised.  cx.st points at
                      // 16 u64 accumulators of THIS wave in LDS (hrt_stream.hip); the first active lane adds the wave's clocks
 typedef unsigned long long __attribute__((address_space(3))) *lu64;
-#define WSEG_ADD(k, v) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) ((lu64)(uint32_t)(uintptr_t)cx.st)[k] += (unsigned long long)(v); } while (0)
+#define WSEG_ADD(k, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) ((lu64)(uint32_t)(uintptr_t)cx.st)[k] += v_; } while (0)
 #define WSEG_START() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long wseg_last = __builtin_readcyclecounter()
 #define WSEG(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
                      WSEG_ADD(k, t_ - wseg_last); wseg_last = t_; } while (0)
@@ -136,84 +136,104 @@ typedef unsigned long long __attribute__((address_space(3))) *lu64;
 #define WSEG(k) do { } while (0)
 #define WCOUNT(k, v) do { } while (0)
 #endif
+// Start of a walk: the mesh's irregular triangles (not in the tree) and the clip of the ray to the root cell.  False: the ray
+// misses the tree, w.best_* is final.
 template <class CX, class MP>  // cmesh: wave-uniform mesh, scalar record loads; gmesh: every lane its own mesh, vector loads
-__device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3 inv, Walk &w, int trips) {
-    WSEG_START();
-    if (w.ref == HRT_KD_NIL) {  // start: clip the ray to the root cell
-        float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
-        float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
-        t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
-        t0 = (M->kd_lo[1] - ray.o.y) * inv.y; t1 = (M->kd_hi[1] - ray.o.y) * inv.y;
-        t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
-        t0 = (M->kd_lo[2] - ray.o.z) * inv.z; t1 = (M->kd_hi[2] - ray.o.z) * inv.z;
-        t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
-        w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
-        (void)mesh_exceptions<CX::exact>(cx, M, ray, inv, w.best_t, w.best_tri, w.bu, w.bv);  // irregular triangles first (not in the tree)
-        if (!(t_entry <= t_scene_exit)) return true;
-        w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
+__device__ __forceinline__ bool mesh_walk_start(const CX &cx, MP M, const Ray &ray, f3 inv, Walk &w) {
+    float t_entry = 0.f, t_scene_exit = HRT_FLT_MAX;
+    float t0 = (M->kd_lo[0] - ray.o.x) * inv.x, t1 = (M->kd_hi[0] - ray.o.x) * inv.x;
+    t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
+    t0 = (M->kd_lo[1] - ray.o.y) * inv.y; t1 = (M->kd_hi[1] - ray.o.y) * inv.y;
+    t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
+    t0 = (M->kd_lo[2] - ray.o.z) * inv.z; t1 = (M->kd_hi[2] - ray.o.z) * inv.z;
+    t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
+    w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
+    (void)mesh_exceptions<CX::exact>(cx, M, ray, inv, w.best_t, w.best_tri, w.bu, w.bv);  // irregular triangles first
+    if (!(t_entry <= t_scene_exit)) return false;
+    w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
+    return true;
+}
+// The state of a walk between trips, unpacked
+struct WalkCursor {
+    uint32_t ref, k, count;
+    float t_entry;
+    f3 p;
+    __device__ __forceinline__ void open(const Walk &w, const Ray &ray) {
+        ref = w.ref; k = w.kk & 0xFFFFu; count = w.kk >> 16; t_entry = w.t_entry;
+        p = ray.o + t_entry * ray.d;
     }
-    WSEG(4);  // start of a walk: root clip, irregular triangles
+    __device__ __forceinline__ void close(Walk &w) const { w.ref = ref; w.t_entry = t_entry; w.kk = (count << 16) | k; }
+};
+// One trip: descend <= HRT_WALK_LEVELS treelets, then enter the leaf / test up to HRT_LEAF_BATCH of its triangles / leave it
+// through a rope (mesh_traverse's loop body, KDTree.cpp:31-85 semantics).  c.ref == HRT_KD_NIL afterwards: the walk is complete.
+template <class CX>
+__device__ __forceinline__ void kd_trip(const CX &cx, gu4 g_units, const Soup &sp, uint32_t tri_base, const Ray &ray, f3 inv, WalkCursor &c, Walk &w) {
+    WSEG_START();
+    WCOUNT(8, 1); WCOUNT(11, __popcll(__ballot(true)));
+#pragma unroll
+    for (int lvl = 0; lvl < HRT_WALK_LEVELS; ++lvl)
+        if (!(c.ref & HRT_KD_LEAF)) c.ref = kd_descend(g_units, cx, c.ref, c.p, ray.d);  // two levels each
+    WSEG(0);  // descent
+    if (c.ref & HRT_KD_LEAF) {
+        WCOUNT(9, 1); WCOUNT(5, __popcll(__ballot(true)));
+        const uint32_t lu = c.ref & ~HRT_KD_LEAF;
+#if HRT_WALK_ROPES
+        uint4 l0, l1, rp0, rp1;
+        kd_fetch4(g_units, cx, lu, l0, l1, rp0, rp1);
+#else
+        uint4 l0, l1;
+        kd_fetch2(g_units, cx, lu, l0, l1);
+#endif
+        const uint32_t first = tri_base + l0.w, cnt = l1.w;
+        WSEG(1);  // leaf nodelets
+        if (c.k == 0xFFFFu) c.k = 0;
+        if (c.k < cnt) {
+            WCOUNT(10, 1); WCOUNT(6, __popcll(__ballot(true)));
+            bool found_ = false;
+            c.k = tri_test_run(sp, first, cnt, c.k, ray, w.best_t, w.best_tri, w.bu, w.bv, found_);
+        }
+        WSEG(2);  // triangles
+        if (c.k >= cnt) {  // leave the cell through its exit face
+            const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
+            const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
+            const float ez = ((ray.d.z > 0.f ? __uint_as_float(l1.z) : __uint_as_float(l0.z)) - ray.o.z) * inv.z;
+            float t_exit = HRT_FLT_MAX;
+            uint32_t face = 6;
+            if (ray.d.x != 0.f && ex < t_exit) { t_exit = ex; face = ray.d.x > 0.f ? 1u : 0u; }
+            if (ray.d.y != 0.f && ey < t_exit) { t_exit = ey; face = ray.d.y > 0.f ? 3u : 2u; }
+            if (ray.d.z != 0.f && ez < t_exit) { t_exit = ez; face = ray.d.z > 0.f ? 5u : 4u; }
+            if (w.best_t <= t_exit || face == 6) {
+                c.ref = HRT_KD_NIL;  // the closest hit lies inside the cells already visited
+            } else {
+                c.t_entry = fmaxf(c.t_entry, t_exit);
+                c.p = ray.o + c.t_entry * ray.d;
+#if HRT_WALK_ROPES
+                const uint4 rp = (face >> 2) ? rp1 : rp0;
+#else
+                const uint4 rp = kd_fetch(g_units, cx, lu + 2 + (face >> 2));
+#endif
+                const uint32_t sel = face & 3u;
+                c.ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
+                c.k = 0xFFFFu;
+                if (++c.count >= HRT_WALK_CELLS) c.ref = HRT_KD_NIL;  // mesh_traverse's bound on the cells of one walk
+            }
+        }
+        WSEG(3);  // exit face, rope
+    }
+}
+// Up to `trips` trips of the walk of mesh M; true when the walk is complete: w.best_* then hold the mesh's closest triangle
+// with t >= 0, if any.
+template <class CX, class MP>
+__device__ __forceinline__ bool mesh_walk(const CX &cx, MP M, const Ray &ray, f3 inv, Walk &w, int trips) {
+    if (w.ref == HRT_KD_NIL && !mesh_walk_start(cx, M, ray, inv, w)) return true;
     gu4 g_units = (gu4)cx.S->kd_units;
     const Soup sp = soup_of(cx.S);
     const uint32_t tri_base = M->tri_base;
-    uint32_t ref = w.ref, k = w.kk & 0xFFFFu, count = w.kk >> 16;
-    float t_entry = w.t_entry;
-    f3 p = ray.o + t_entry * ray.d;
-    for (int trip = 0; trip < trips && ref != HRT_KD_NIL; ++trip) {
-        WCOUNT(8, 1); WCOUNT(11, __popcll(__ballot(true)));
-#pragma unroll
-        for (int lvl = 0; lvl < HRT_WALK_LEVELS; ++lvl)
-            if (!(ref & HRT_KD_LEAF)) ref = kd_descend(g_units, cx, ref, p, ray.d);  // two levels each
-        WSEG(0);  // descent
-        if (ref & HRT_KD_LEAF) {
-            WCOUNT(9, 1); WCOUNT(5, __popcll(__ballot(true)));
-            const uint32_t lu = ref & ~HRT_KD_LEAF;
-#if HRT_WALK_ROPES
-            uint4 l0, l1, rp0, rp1;
-            kd_fetch4(g_units, cx, lu, l0, l1, rp0, rp1);
-#else
-            uint4 l0, l1;
-            kd_fetch2(g_units, cx, lu, l0, l1);
-#endif
-            const uint32_t first = tri_base + l0.w, cnt = l1.w;
-            WSEG(1);  // leaf nodelets
-            if (k == 0xFFFFu) k = 0;
-            if (k < cnt) {
-                WCOUNT(10, 1); WCOUNT(6, __popcll(__ballot(true)));
-                bool found_ = false;
-                k = tri_test_run(sp, first, cnt, k, ray, w.best_t, w.best_tri, w.bu, w.bv, found_);
-            }
-            WSEG(2);  // triangles
-            if (k >= cnt) {  // leave the cell through its exit face
-                const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
-                const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
-                const float ez = ((ray.d.z > 0.f ? __uint_as_float(l1.z) : __uint_as_float(l0.z)) - ray.o.z) * inv.z;
-                float t_exit = HRT_FLT_MAX;
-                uint32_t face = 6;
-                if (ray.d.x != 0.f && ex < t_exit) { t_exit = ex; face = ray.d.x > 0.f ? 1u : 0u; }
-                if (ray.d.y != 0.f && ey < t_exit) { t_exit = ey; face = ray.d.y > 0.f ? 3u : 2u; }
-                if (ray.d.z != 0.f && ez < t_exit) { t_exit = ez; face = ray.d.z > 0.f ? 5u : 4u; }
-                if (w.best_t <= t_exit || face == 6) {
-                    ref = HRT_KD_NIL;  // the closest hit lies inside the cells already visited
-                } else {
-                    t_entry = fmaxf(t_entry, t_exit);
-                    p = ray.o + t_entry * ray.d;
-#if HRT_WALK_ROPES
-                    const uint4 rp = (face >> 2) ? rp1 : rp0;
-#else
-                    const uint4 rp = kd_fetch(g_units, cx, lu + 2 + (face >> 2));
-#endif
-                    const uint32_t sel = face & 3u;
-                    ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
-                    k = 0xFFFFu;
-                    if (++count >= HRT_WALK_CELLS) ref = HRT_KD_NIL;  // mesh_traverse's bound on the cells of one walk
-                }
-            }
-            WSEG(3);  // exit face, rope
-        }
-    }
-    w.ref = ref; w.t_entry = t_entry; w.kk = (count << 16) | k;
-    return ref == HRT_KD_NIL;
+    WalkCursor c;
+    c.open(w, ray);
+    for (int trip = 0; trip < trips && c.ref != HRT_KD_NIL; ++trip) kd_trip(cx, g_units, sp, tri_base, ray, inv, c, w);
+    c.close(w);
+    return c.ref == HRT_KD_NIL;
 }
 
 // Up to `trips` trips on each mesh still to be walked, in mesh order (Scene.h:222-228); a finished mesh is merged
@@ -241,23 +261,41 @@ __device__ __forceinline__ bool walk_some(const CX &cx, const Ray &ray, uint32_t
     return parked == 0u;
 }
 
-// The same with every lane on ITS next mesh at once (per-lane mesh records): lanes that wait for different meshes
-// of a multi-mesh scene walk in the same trips instead of taking turns.  Results cannot differ: a walk depends
-// only on its ray and its mesh.
+// The same with every lane on ITS next mesh at once (per-lane mesh records), in ONE flat loop of `trips` steps: a step is
+// either the start of the lane's next mesh (irregular triangles, root clip) or one trip of the walk in progress; a finished
+// mesh is merged and the lane moves on to its next one in the following step.  (Giving every mesh its own `trips` trips made a
+// visit as long as its slowest lane's meshes together: 20 of 64 lanes active per trip on the three-mesh pool scene.)  Results
+// cannot differ: a walk depends only on its ray and its mesh, and a lane's meshes are still merged in mesh order.
 template <class CX>
 __device__ __forceinline__ bool walk_some_per_lane(const CX &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int trips) {
     if (CX::exact && (cx.flags & HRT_FLAG_MESH_BRUTE)) return walk_some(cx, ray, parked, w, h, trips);
     const f3 inv = ray_inv<CX::exact>(ray);
     const typename CX::tabmesh meshes = cx.tmesh;
-    while (parked != 0u) {
+    gu4 g_units = (gu4)cx.S->kd_units;
+    const Soup sp = soup_of(cx.S);
+    WalkCursor c;
+    c.open(w, ray);
+    for (int step = 0; step < trips && parked != 0u; ++step) {
         const uint32_t i = (uint32_t)__builtin_ctz(parked);
-        if (!mesh_walk(cx, meshes + i, ray, inv, w, trips)) break;  // out of trips: resume here next visit
-        const float t = w.best_t;
-        if (t < HRT_FLT_MAX && t < h.t && HRT_T_ACCEPT(t)) {
-            h.kind = 3; h.index = i; h.t = t; h.tri = w.best_tri; h.a0 = w.bu; h.a1 = w.bv;
+        const typename CX::tabmesh M = meshes + i;
+        bool finished;
+        if (c.ref == HRT_KD_NIL) {  // no walk in progress: start this lane's next mesh
+            finished = !mesh_walk_start(cx, M, ray, inv, w);
+            if (!finished) c.open(w, ray);
+        } else {
+            kd_trip(cx, g_units, sp, M->tri_base, ray, inv, c, w);
+            finished = c.ref == HRT_KD_NIL;
         }
-        parked &= parked - 1u;
+        if (finished) {
+            const float t = w.best_t;
+            if (t < HRT_FLT_MAX && t < h.t && HRT_T_ACCEPT(t)) {
+                h.kind = 3; h.index = i; h.t = t; h.tri = w.best_tri; h.a0 = w.bu; h.a1 = w.bv;
+            }
+            parked &= parked - 1u;
+            c.ref = HRT_KD_NIL;
+        }
     }
+    c.close(w);
     return parked == 0u;
 }
 
