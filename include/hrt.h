@@ -100,9 +100,10 @@ typedef struct hrt_light {
  *   leaf  nodelet (4 units): { bmin.xyz, u32 tri_first | bmax.xyz, u32 tri_count |
  *                              rope[-x,+x,-y,+y] | rope[-z,+z], 0, 0 }
  * tri_first/tri_count index leaf_tris[] (triangle ids of the mesh).
- * Any numbering is valid.  The host builder keeps a node and its inner children inside one 64-byte line, starts leaves on
- * 64-byte boundaries (unused padding units are zero) and emits these clusters breadth-first, so that a prefix of the
- * array is the top of the tree (that prefix is what the kernels stage into LDS). */
+ * Any numbering is valid: hrt_scene_create re-lays the reachable part of the tree for its walk (two-level treelets,
+ * breadth-first, so that a prefix of ITS array is the top of the tree -- what the kernels stage into LDS).  The host
+ * builder keeps a node and its inner children inside one 64-byte line and starts leaves on 64-byte boundaries (unused
+ * padding units are zero), which is what the CPU-side walks of the same array like. */
 #define HRT_KD_LEAF 0x80000000u
 #define HRT_KD_NIL 0xFFFFFFFFu
 typedef struct hrt_kdunit {
@@ -115,8 +116,8 @@ typedef struct hrt_kdunit {
  * near-degenerate slivers, whose barycentric test (Triangle.h:62-75) accepts phantom points far outside the triangle.
  * Those triangles are kept OUT of the flattened tree (not listed in leaf_tris) and tested exactly when the reference
  * would: when AABB::intersects (AABB.h:48-65) passes for the box of one of the reference leaves that hold them.
- * One entry per (triangle, reference leaf box) pair, in any order; hrt_scene_create groups them by box and builds a
- * small bounding hierarchy over the distinct boxes. */
+ * One entry per (triangle, reference leaf box) pair, in any order; hrt_scene_create groups them by triangle under a small
+ * bounding hierarchy: a ray tests such a triangle at most once, and asks its boxes only for a hit closer than the best. */
 typedef struct hrt_tri_exception {
     uint32_t triangle;           /* triangle id of the mesh */
     float box_min[3], box_max[3];
