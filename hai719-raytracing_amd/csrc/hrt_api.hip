@@ -477,6 +477,24 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         };
         if (M.n_leaf_tris) {
             if (M.kd_root == HRT_KD_NIL || !in_range(M.kd_root)) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree");
+            {   // the child links must form a TREE: a nodelet reached twice (a shared subtree, or a cycle -- on which a walk would
+                // descend forever) is refused
+                std::vector<uint8_t> reached(M.n_kd_units, 0);
+                std::vector<uint32_t> stack{M.kd_root};
+                reached[M.kd_root & ~HRT_KD_LEAF] = 1;
+                while (!stack.empty()) {
+                    const uint32_t ref = stack.back();
+                    stack.pop_back();
+                    if (ref & HRT_KD_LEAF) continue;
+                    const hrt_kdunit &u = M.kd_units[ref];
+                    for (int c = 2; c < 4; ++c) {
+                        const uint32_t child = u.w[c];
+                        if (child == HRT_KD_NIL || !in_range(child) || reached[child & ~HRT_KD_LEAF]) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree (a nodelet is reached twice through child links)");
+                        reached[child & ~HRT_KD_LEAF] = 1;
+                        stack.push_back(child);
+                    }
+                }
+            }
             std::vector<uint32_t> new_of(M.n_kd_units, 0xFFFFFFFFu);  // caller's unit index -> unit index in this mesh's new list
             std::vector<uint32_t> order;                               // caller's refs in the order they are laid out
             uint32_t cur = 0;
