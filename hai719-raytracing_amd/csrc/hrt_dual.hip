@@ -149,8 +149,9 @@ __device__ __forceinline__ bool mesh_walk_start(const CX &cx, MP M, const Ray &r
     t_entry = fmaxf(t_entry, fminf(t0, t1)); t_scene_exit = fminf(t_scene_exit, fmaxf(t0, t1));
     w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
     (void)mesh_exceptions<CX::exact>(cx, M, ray, inv, w.best_t, w.best_tri, w.bu, w.bv);  // irregular triangles first
-    if (!(t_entry <= t_scene_exit)) return false;
-    w.ref = M->root; w.t_entry = t_entry; w.kk = 0xFFFFu;
+    const uint32_t root = M->root;
+    if (!(t_entry <= t_scene_exit) || root == HRT_KD_NIL) return false;  // (a mesh whose triangles are all irregular or dead has no tree)
+    w.ref = root; w.t_entry = t_entry; w.kk = 0xFFFFu;
     return true;
 }
 // The state of a walk between trips, unpacked

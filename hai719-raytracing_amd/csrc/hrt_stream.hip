@@ -15,15 +15,18 @@
 // G and H hand the path to T when its ray enters a mesh box, else to the hit queue of its kind; T does the same
 // when the walk is complete.  Sorting by kind makes a chunk run ONE branch of shade().  Queues are double-
 // buffered: a cycle consumes the "in" buffers, frozen at its start, and appends to the "out" buffers, so all
-// stages run in the SAME cycle between one pair of barriers; the 16 waves pull chunks from one LDS cursor
-// (T first: the longest).  Appends are wave-aggregated: one __ballot, one LDS atomicAdd by the leader lane,
-// positions by popcount of the lower lanes (__shfl of the base).  With 4096 paths a cycle offers ~64 chunks,
-// so the waves' wait at the cycle barrier is ~8 % (it was 62 % with the 1024-path pool that fits in LDS).
+// stages run in the SAME cycle; the 16 waves pull chunks from one LDS cursor (T first: the longest).  Appends
+// are wave-aggregated: one __ballot, one LDS atomicAdd by the leader lane, positions by popcount of the lower
+// lanes (__shfl of the base).
 //
-// Every control value is written by thread 0 between two barriers and read back through readfirstlane, so all
-// loops around the barriers are provably wave-uniform for the compiler.  (With per-thread copies of the same
-// values hipcc if-converted the loop exits into exec masks and waves left the barrier sequence at different
-// points: wrong pixels, hangs.)  A cycle bound (1 << 16) ends a run that a scheduling bug would otherwise spin.
+// The pool is split into HRT_SP_STREAMS = 2 streams, each with its own slots, queues and cycle counter, and there is
+// no barrier inside a fold: a wave that finds no chunk left in a stream's cycle ARRIVES (an LDS counter) and goes on
+// with the other stream; the wave whose arrival completes the cycle runs the serial section (new path numbers, buffer
+// swap, unused free slots) and publishes the next cycle (see the comment at the scheduler, below).  Every control
+// value a loop condition depends on is read back through readfirstlane, so those loops are provably wave-uniform
+// for the compiler.  (With per-thread copies of the same values hipcc if-converted the loop exits into exec masks
+// and waves left the rendezvous sequence at different points: wrong pixels, hangs.)  A cycle bound (1 << 16) and
+// bounded spins end a run that a scheduling bug would otherwise spin; the host then reports HRT_ERR_DEVICE.
 //
 // DETERMINISM.  A path is keyed (pixel, sample) as before, so the schedule cannot change its random numbers or
 // its arithmetic.  A work unit is up to 16 tiles x 64 pixels x the samples of one fold (<= HRT_SP_UNIT paths);
