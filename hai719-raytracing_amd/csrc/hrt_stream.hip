@@ -87,8 +87,8 @@ enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_HT, SP_HID, SP_HA0, SP_H
        SP_FIELDS };  // 32 dwords: one 128-byte record
 
 struct SpCtl {           // control block of ONE stream in LDS (24 dwords)
-    uint32_t cT[2], cF[2];   // queue fills, [parity]
-    uint32_t cK[4][2];       // closest-hit queues by hit kind (0 miss, 1 sphere, 2 square, 3 mesh), [kind][parity]
+    uint32_t cQ[6][2];       // queue fills, [queue][parity]: 0 = T, 1..4 = the closest-hit queues by hit kind (0 miss, 1 sphere, 2 square,
+                             // 3 mesh), 5 = free slots.  Contiguous: sp_push_all addresses them by queue number
     uint32_t cursor;         // chunk cursor of the running cycle
     uint32_t ngen, gen_n0;   // new paths of the running cycle and the number of the first one
     uint32_t done, parity, cycles;
@@ -179,35 +179,32 @@ __device__ __forceinline__ void sp_store_ray_hit(const SpLds &L, uint32_t slot, 
 }
 __device__ __forceinline__ uint16_t *spq(const SpLds &L, int which, uint32_t parity) { return L.q + (2 * which + parity) * HRT_SP_QCAP; }
 
-// Wave-aggregated append of `slot` for the lanes with `want`: __ballot + one LDS atomic by the leader.
-__device__ __forceinline__ void sp_push(uint16_t *q, uint32_t *count, bool want, uint32_t slot) {
-    const uint64_t m = __ballot(want);
-    if (m == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, (int)leader);
-    if (want) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)slot;
-}
-
-// Append to the closest-hit queue of the path's hit kind: chunks of the next cycle are then homogeneous in kind, so a
-// chunk runs ONE of shade()'s branches (and mostly one of scatter()'s) instead of all of them.
-__device__ __forceinline__ void sp_push_hit(const SpLds &L, SpCtl &C, uint32_t out, bool want, uint32_t kind, uint32_t slot) {
+// All appends of a chunk at once.  Every lane names the queue its path goes to (`to`: 0 = T, 1..4 = closest hit of kind
+// to - 1, 5 = free list, SP_TO_NONE = nowhere); ONE LDS atomic, issued by the first lane of each queue on that queue's counter,
+// reserves the entries, one ds_bpermute hands the bases round, one write stores the slot ids.  (One sp_push per queue was a
+// chain of up to six atomic-with-return / shuffle pairs per chunk.)
+#define SP_TO_NONE 6u
+__device__ __forceinline__ void sp_push_all(const SpLds &L, SpCtl &C, uint32_t out, uint32_t to, uint32_t slot) {
+    uint32_t rank = 0, count = 0, leader = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) {
-        const uint64_t m = __ballot(want && kind == k);
-        if (m == 0ull) continue;
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&C.cK[k][out], (uint32_t)__popcll(m));
-        base = __shfl(base, (int)leader);
-        if (want && kind == k) {
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            uint16_t *q = spq(L, (k == 1u || k == 2u) ? 1 : 2, out);
-            q[(k == 1u || k == 0u) ? pos : (uint32_t)HRT_SP_QCAP - 1u - pos] = (uint16_t)slot;
+    for (uint32_t q = 0; q < 6u; ++q) {
+        const uint64_t m = __ballot(to == q);
+        if (to == q) {
+            rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            count = (uint32_t)__popcll(m);
+            leader = (uint32_t)__builtin_ctzll(m | (1ull << 63));
         }
+    }
+    uint32_t base = 0;
+    if (to < SP_TO_NONE && rank == 0u) base = atomicAdd(&C.cQ[to][out], count);
+    base = __shfl(base, (int)leader);
+    if (to < SP_TO_NONE) {
+        const uint32_t pos = base + rank;
+        // buffers (spq): T -> 0 from the front; kinds 1 (sphere) and 2 (square) share 1, kinds 0 (miss) and 3 (mesh) share 2, the
+        // first of each pair from the front, the second from the back; free slots -> 3
+        const uint32_t buf = to == 0u ? 0u : (to == 5u ? 3u : ((to == 2u || to == 3u) ? 1u : 2u));
+        const bool back = to == 3u || to == 4u;
+        spq(L, (int)buf, out)[back ? (uint32_t)HRT_SP_QCAP - 1u - pos : pos] = (uint16_t)slot;
     }
 }
 
@@ -282,9 +279,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     uint16_t *const q_all = L.q;
     if (tid < HRT_SP_STREAMS) {
         SpCtl &C0 = L.ctl[tid];
-        C0.cT[0] = C0.cT[1] = 0;
-        for (int k = 0; k < 4; ++k) C0.cK[k][0] = C0.cK[k][1] = 0;
-        C0.cF[0] = HRT_SP_QCAP; C0.cF[1] = 0;
+        C0.cQ[0][0] = C0.cQ[0][1] = 0;
+        for (int k = 0; k < 4; ++k) C0.cQ[1 + k][0] = C0.cQ[1 + k][1] = 0;
+        C0.cQ[5][0] = HRT_SP_QCAP; C0.cQ[5][1] = 0;
         C0.parity = 1; C0.cycles = 0; C0.done = 0; C0.arrive = 0; C0.ready = 0; C0.cursor = 0; C0.ngen = 0; C0.gen_n0 = 0;
         if (tid == 0) { SH.gen_next = 0; SH.gen_total = 0; SH.tile = 0; SH.abort = 0; }
     }
@@ -349,7 +346,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             // stage of the same stream, so there is no cyclic wait.  Every wait is bounded (abort -> HRT_ERR_DEVICE on the host).
             auto serial_section = [&](SpCtl &C, uint16_t *qs) {  // one whole wave; control values by lane 0
                 const uint32_t par = SP_UNI(C.parity) ^ 1u;  // the buffers the finished cycle appended to become the input
-                const uint32_t free_in = SP_UNI(C.cF[par]);
+                const uint32_t free_in = SP_UNI(C.cQ[5][par]);
 #if HRT_SP_DEFER
                 const uint32_t want = free_in & ~63u;  // whole chunks of new paths only (the last paths of the fold come as they are)
 #else
@@ -367,12 +364,12 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 // path is advanced changes nothing -- and the chunks that do run have all 64 lanes filled.  Once every path of the
                 // fold has been started, everything runs (the stream drains).
                 const bool defer = HRT_SP_DEFER && old + ngen < total_paths;
-                const uint32_t cT = SP_UNI(C.cT[par]), rT = defer ? (cT & 63u) : 0u;
+                const uint32_t cT = SP_UNI(C.cQ[0][par]), rT = defer ? (cT & 63u) : 0u;
                 if (lane < rT) qs[(2 * 0 + (par ^ 1u)) * HRT_SP_QCAP + lane] = qs[(2 * 0 + par) * HRT_SP_QCAP + cT - rT + lane];
                 uint32_t cKv[4], rK[4], waiting = cT;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    cKv[k] = SP_UNI(C.cK[k][par]);
+                    cKv[k] = SP_UNI(C.cQ[1 + k][par]);
                     rK[k] = defer ? (cKv[k] & 63u) : 0u;
                     waiting += cKv[k];
                     const int which = (k == 1 || k == 2) ? 1 : 2;  // the addressing of sp_push_hit: kinds 1 and 0 from the front, 2 and 3 from the back
@@ -386,10 +383,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 }
                 if (lane == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { C.cK[k][par] = cKv[k] - rK[k]; C.cK[k][par ^ 1u] = rK[k]; }
-                    C.cT[par] = cT - rT;
-                    C.cT[par ^ 1u] = rT;
-                    C.cF[par ^ 1u] = free_in - ngen;  // the unused free slots carry over, freed slots are appended after them
+                    for (int k = 0; k < 4; ++k) { C.cQ[1 + k][par] = cKv[k] - rK[k]; C.cQ[1 + k][par ^ 1u] = rK[k]; }
+                    C.cQ[0][par] = cT - rT;
+                    C.cQ[0][par ^ 1u] = rT;
+                    C.cQ[5][par ^ 1u] = free_in - ngen;  // the unused free slots carry over, freed slots are appended after them
                     C.ngen = ngen; C.gen_n0 = old; C.cursor = 0; C.parity = par;
                     C.done = (ngen == 0u && waiting == 0u) ? 1u : 0u;  // nothing in flight and nothing left to start: the stream has drained
                     if (++C.cycles > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
@@ -448,16 +445,15 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 if (SP_UNI(C.done)) { fin_mask |= 1u << st; continue; }
                 const uint32_t parity = SP_UNI(C.parity);
                 const uint32_t ngen = SP_UNI(C.ngen), n0 = SP_UNI(C.gen_n0);
-                const uint32_t cTin = SP_UNI(C.cT[parity]);
-                const uint32_t cK0 = SP_UNI(C.cK[0][parity]), cK1 = SP_UNI(C.cK[1][parity]), cK2 = SP_UNI(C.cK[2][parity]),
-                               cK3 = SP_UNI(C.cK[3][parity]);
+                const uint32_t cTin = SP_UNI(C.cQ[0][parity]);
+                const uint32_t cK0 = SP_UNI(C.cQ[1][parity]), cK1 = SP_UNI(C.cQ[2][parity]), cK2 = SP_UNI(C.cQ[3][parity]),
+                               cK3 = SP_UNI(C.cQ[4][parity]);
                 // chunk ranges of this cycle: T (longest) first, then mesh, sphere, square hits, misses, new paths last
                 const uint32_t nT = HRT_SP_THALF ? (cTin + 31u) >> 5 : (cTin + 63u) >> 6, e3 = nT + ((cK3 + 63u) >> 6), e1 = e3 + ((cK1 + 63u) >> 6),
                                e2 = e1 + ((cK2 + 63u) >> 6), e0 = e2 + ((cK0 + 63u) >> 6), nG = (ngen + 63u) >> 6, total = e0 + nG;
-                uint16_t *qTi = spq(L, 0, parity), *qTo = spq(L, 0, parity ^ 1u);
+                uint16_t *qTi = spq(L, 0, parity);
                 uint16_t *qAi = spq(L, 1, parity), *qBi = spq(L, 2, parity);
-                uint16_t *qFi = spq(L, 3, parity), *qFo = spq(L, 3, parity ^ 1u);
-                uint32_t *cTo = &C.cT[parity ^ 1u], *cFo = &C.cF[parity ^ 1u];
+                uint16_t *qFi = spq(L, 3, parity);
 #ifdef HRT_SP_DEBUG
                 const unsigned long long dbg_w0 = __builtin_readcyclecounter();
                 ++dbg_cycles;
@@ -521,8 +517,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             }
                             kind = h.kind;
                         }
-                        sp_push(qTo, cTo, act && !walked, slot);  // unfinished: joins the next cycle's T chunks
-                        sp_push_hit(L, C, parity ^ 1u, act && walked, kind, slot);
+                        // unfinished: joins the next cycle's T chunks; finished: the closest-hit queue of its kind
+                        sp_push_all(L, C, parity ^ 1u, !act ? SP_TO_NONE : (walked ? 1u + kind : 0u), slot);
                         SEG(2);  // T: stores + appends
 #ifdef HRT_SP_SEG
                         if (seg_on) { seg[7] += 1; seg[6] += (unsigned long long)__popcll(__ballot(act)); seg[5] += (unsigned long long)__popcll(__ballot(act && walked)); }
@@ -630,9 +626,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                             to_mesh = pmn != 0u;
                             kind = hn.kind;
                         }
-                        sp_push(qTo, cTo, trace && to_mesh, slot);
-                        sp_push_hit(L, C, parity ^ 1u, trace && !to_mesh, kind, slot);
-                        sp_push(qFo, cFo, freed, slot);
+                        sp_push_all(L, C, parity ^ 1u, trace ? (to_mesh ? 0u : 1u + kind) : (freed ? 5u : SP_TO_NONE), slot);
                         SEG(6);  // record stores + queue appends
 #ifdef HRT_SP_SEG
                         if (seg_on) seg[7] += 1;
