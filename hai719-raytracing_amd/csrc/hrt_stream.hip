@@ -208,30 +208,6 @@ __device__ __forceinline__ void sp_push_all(const SpLds &L, SpCtl &C, uint32_t o
     }
 }
 
-__device__ __forceinline__ Ray sp_load_ray(const SpLds &L, uint32_t slot) {
-    Ray ray;
-    ray.o = mk(spf(L, SP_OX, slot), spf(L, SP_OY, slot), spf(L, SP_OZ, slot));
-    ray.d = mk(spf(L, SP_DX, slot), spf(L, SP_DY, slot), spf(L, SP_DZ, slot));
-    ray.time = spf(L, SP_TM, slot);
-    return ray;
-}
-__device__ __forceinline__ void sp_store_ray(const SpLds &L, uint32_t slot, const Ray &ray) {
-    spf(L, SP_OX, slot) = ray.o.x; spf(L, SP_OY, slot) = ray.o.y; spf(L, SP_OZ, slot) = ray.o.z;
-    spf(L, SP_DX, slot) = ray.d.x; spf(L, SP_DY, slot) = ray.d.y; spf(L, SP_DZ, slot) = ray.d.z;
-}
-__device__ __forceinline__ void sp_store_hit(const SpLds &L, uint32_t slot, const Hit &h, uint32_t pm) {
-    spu(L, SP_HID, slot) = (h.kind << 28) | h.index;
-    spf(L, SP_HT, slot) = h.t; spf(L, SP_HA0, slot) = h.a0; spf(L, SP_HA1, slot) = h.a1;
-    spu(L, SP_HTRI, slot) = h.tri; spu(L, SP_PM, slot) = pm;
-}
-__device__ __forceinline__ Hit sp_load_hit(const SpLds &L, uint32_t slot) {
-    Hit h;
-    const uint32_t hid = spu(L, SP_HID, slot);
-    h.kind = hid >> 28; h.index = hid & 0x0FFFFFFFu; h.t = spf(L, SP_HT, slot);
-    h.tri = spu(L, SP_HTRI, slot); h.a0 = spf(L, SP_HA0, slot); h.a1 = spf(L, SP_HA1, slot);
-    return h;
-}
-
 template <bool LIGHTS, bool EXACT = false>
 __device__ __forceinline__ void stream_body(const DRender &R) {
     extern __shared__ uint4 s_raw[];
