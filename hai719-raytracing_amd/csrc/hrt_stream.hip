@@ -284,7 +284,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #define SEG(k) do { } while (0)
 #endif
 #ifdef HRT_SP_DEBUG
-    unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0, dbg_wait = 0, dbg_drain = 0;
+    unsigned long long dbg_work = 0, dbg_chunks = 0, dbg_cycles = 0, dbg_serial = 0, dbg_wait = 0, dbg_drain = 0, dbg_tail = 0, dbg_tail_cycles = 0;
     unsigned long long dbg_class[6] = {0, 0, 0, 0, 0, 0};  // clocks in T, mesh-hit, sphere-hit, square-hit, miss, G chunks
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
 #endif
@@ -614,6 +614,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 }
 #ifdef HRT_SP_DEBUG
                 dbg_work += __builtin_readcyclecounter() - dbg_w0;
+                if (ngen == 0u) { dbg_tail += __builtin_readcyclecounter() - dbg_w0; ++dbg_tail_cycles; }  // cycles of the drain: nothing left to start
 #endif
                 // this wave's part of the cycle is done: its records are in memory and its queue entries in LDS before it arrives
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -683,7 +684,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         atomicAdd(R.stamps + 0, dbg_work); atomicAdd(R.stamps + 1, __builtin_readcyclecounter() - dbg_t0);
         atomicAdd(R.stamps + 2, dbg_cycles); atomicAdd(R.stamps + 3, dbg_chunks); atomicAdd(R.stamps + 4, dbg_serial);
         for (int k = 0; k < 6; ++k) atomicAdd(R.stamps + 5 + k, dbg_class[k]);  // [5..10] clocks per chunk class
-        atomicAdd(R.stamps + 11, dbg_wait); atomicAdd(R.stamps + 12, dbg_drain);  // waiting for a stream's next cycle; at the barrier that ends a fold
+        atomicAdd(R.stamps + 11, dbg_wait); atomicAdd(R.stamps + 12, dbg_drain); atomicAdd(R.stamps + 13, dbg_tail); atomicAdd(R.stamps + 14, dbg_tail_cycles);  // waiting for a stream's next cycle; at the barrier that ends a fold
     }
 #endif
 #undef SP_UNI
