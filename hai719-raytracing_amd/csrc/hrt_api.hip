@@ -934,7 +934,7 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
                              !(flags & HRT_FLAG_WAVE_KERNEL);
     uint32_t grid, lds_bytes;
     if (stream_kernel) {
-        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_STREAMS * sizeof(SpCtl) + sizeof(SpShared) + HRT_SP_MAXG * 192 * 4 + HRT_SP_MAXG * 4) +
+        const uint32_t fixed = (uint32_t)((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_STREAMS * sizeof(SpCtl) + sizeof(SpShared) + HRT_SP_UNITS * sizeof(SpUnit) + HRT_SP_UNITS * HRT_SP_MAXG * 4) +
                                2048u + s->d.tab_rows * 16u  // + the scene's per-object tables (stream_tables_fit)
 #ifdef HRT_WALK_SEG
                                + 2048u  // diagnostic build: 16 accumulators per wave
@@ -952,7 +952,7 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
             while ((2u << glog) <= HRT_SP_MAXG && (per_tile << (glog + 1u)) <= HRT_SP_UNIT) ++glog;
             R.sp_group_log2 = glog;
         }
-        const size_t need_floats = (size_t)grid * HRT_SP_UNIT * 3u;
+        const size_t need_floats = (size_t)grid * HRT_SP_UNITS * HRT_SP_UNIT * 3u;  // HRT_SP_UNITS units in flight per workgroup
         if (s->sp_scratch_cap < need_floats) {
             if (s->sp_scratch) (void)hipFree(s->sp_scratch);
             s->sp_scratch = nullptr; s->sp_scratch_cap = 0;

@@ -51,7 +51,13 @@
 #endif
 #define HRT_SP_SCHUNK 1024 // most samples per pixel traced between two ordered folds
 #ifndef HRT_SP_UNIT
-#define HRT_SP_UNIT 32768  // paths of one work unit = tiles of the group x 64 pixels x samples per fold (scratch: 12 B each)
+#define HRT_SP_UNIT 8192   // most paths of one work unit = tiles of the group x 64 pixels x samples per fold (scratch: 12 B each).  1080p, ms
+                           // Cornell+mesh @256 / pool @256 / Cornell+mesh @16 with units x size: 2 x 16384 -> 186.1 / 348.6 / 12.7, 4 x 8192 -> 186.7 /
+                           // 349.8 / 12.3, 3 x 16384 -> 195.0 / 347.5 / 12.9, 2 x 32768 -> 201.6 / 352.2 / 12.8 (the scratch of all workgroups competes
+                           // with the path pool for the Infinity Cache)
+#endif
+#ifndef HRT_SP_UNITS
+#define HRT_SP_UNITS 4     // work units in flight per workgroup (1..4)
 #endif
 #define HRT_SP_MAXG 16     // most tiles per unit; a power of two
 #ifndef HRT_SP_TRIPS
@@ -86,36 +92,50 @@ enum { SP_OX = 0, SP_OY, SP_OZ, SP_DX, SP_DY, SP_DZ, SP_HT, SP_HID, SP_HA0, SP_H
        SP_TR, SP_TG, SP_TB, SP_RR, SP_RG, SP_RB, SP_RI, SP_REM,  // rewritten by every hit visit: two aligned 16-byte stores
        SP_FIELDS };  // 32 dwords: one 128-byte record
 
-struct SpCtl {           // control block of ONE stream in LDS (24 dwords)
+struct SpCtl {           // control block of ONE stream in LDS (28 dwords)
     uint32_t cQ[6][2];       // queue fills, [queue][parity]: 0 = T, 1..4 = the closest-hit queues by hit kind (0 miss, 1 sphere, 2 square,
                              // 3 mesh), 5 = free slots.  Contiguous: sp_push_all addresses them by queue number
     uint32_t cursor;         // chunk cursor of the running cycle
-    uint32_t ngen, gen_n0;   // new paths of the running cycle and the number of the first one
-    uint32_t done, parity, cycles;
+    uint32_t ngen, gen_n0;   // new paths of the running cycle and the number (within its unit's fold) of the first one
+    uint32_t gen_slot, gen_s0;  // ... the unit slot they belong to and the first sample of that unit's fold
+    uint32_t red_slot;       // unit slot whose finished fold this cycle reduces into the pixel sums (HRT_SP_UNITS: none), with its
+    uint32_t red_j, red_s0, red_ns;  // first tile, first sample and samples per pixel
+    uint32_t more;           // paths will still be started later (partial chunks may wait, see the serial section)
+    uint32_t done, parity;
     uint32_t arrive;         // waves that have finished their part of a cycle of this stream, ever (monotonic)
     uint32_t ready;          // number of the cycle whose control values above are valid (monotonic; waves wait for it)
-    uint32_t pad[4];
+    uint32_t pad[2];
 };
+struct SpUnit {          // a WORK UNIT in flight: G tiles x 64 pixels x the samples of one fold (8 dwords); a workgroup keeps two
+    uint32_t state;          // SP_U_*
+    uint32_t j;              // first tile slot (of this rank's tiles)
+    uint32_t s0, ns;         // the fold: samples [s0, s0 + ns) of every pixel
+    uint32_t gen_next, gen_total;  // paths of the fold handed out / in all
+    uint32_t outstanding;    // paths started and not yet finished (atomic)
+    uint32_t pad;
+};
+enum { SP_U_FREE = 0, SP_U_READY, SP_U_GENERATING, SP_U_DRAINING, SP_U_REDUCING };
 struct SpShared {        // what the streams of a workgroup share (8 dwords)
-    uint32_t gen_next;       // paths of the current fold handed out so far (atomic; may run past gen_total)
-    uint32_t gen_total;      // paths of the current fold
-    uint32_t tile;           // first tile slot of the work unit
+    uint32_t lock;           // the unit bookkeeping of the serial sections (the two streams' can run at the same time)
+    uint32_t cur;            // the unit slot new paths come from
+    uint32_t tiles_done;     // the rank's tile queue is exhausted
     uint32_t abort;          // a bound tripped: every wave leaves the scheduler, the workgroup leaves the kernel
-    uint32_t pad[4];
+    uint32_t stall;          // serial sections since a unit was last opened or reduced (the bound of HRT_SP_CYCLE_BOUND)
+    uint32_t pad[3];
 };
-static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
+static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0 && sizeof(SpUnit) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
 static_assert(HRT_SP_STREAMS == 1 || HRT_SP_STREAMS == 2, "one or two streams");
+static_assert(HRT_SP_UNITS >= 1 && HRT_SP_UNITS <= 4, "a path number carries its unit slot in its two top bits");
 static_assert(HRT_SP_QCAP >= 512, "deferring partial chunks needs a queue that can hold a whole chunk whenever fewer than 64 slots are free (6 queues x 63 < QCAP - 64)");
 
 static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
-static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_MAXG * 196 * 4 + 128 <= 160 * 1024,
+static_assert((HRT_SP_GLOBAL ? 0 : SP_FIELDS * HRT_SP_POOL * 4) + HRT_SP_NQ * HRT_SP_POOL * 2 + HRT_SP_MAXG * 8 + 512 <= 160 * 1024,
               "pool + queues do not fit the CU's 160 KB of LDS (with HRT_SP_GLOBAL=0 use -DHRT_SP_POOL=1024)");
 
 struct SpLds {
     uint32_t *st;        // SP_FIELDS x POOL dwords
     uint16_t *q;         // HRT_SP_NQ queues x HRT_SP_QCAP entries of the stream in hand (streams follow each other)
-    SpCtl *ctl;          // HRT_SP_STREAMS control blocks, then SpShared
-    float *run;          // HRT_SP_MAXG x 64 x 3 running pixel sums of the unit's tiles, then HRT_SP_MAXG packed tile origins
+    SpCtl *ctl;          // HRT_SP_STREAMS control blocks, then SpShared, the two SpUnit, 2 x HRT_SP_MAXG packed tile origins
 };
 
 #if HRT_SP_GLOBAL
@@ -221,9 +241,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #endif
     L.ctl = reinterpret_cast<SpCtl *>(L.q + HRT_SP_NQ * HRT_SP_POOL);
     SpShared &SH = *reinterpret_cast<SpShared *>(L.ctl + HRT_SP_STREAMS);
-    L.run = reinterpret_cast<float *>(&SH + 1);
-    uint32_t *tile_xy = reinterpret_cast<uint32_t *>(L.run + HRT_SP_MAXG * 192);  // x0 | y0 << 16 per tile of the unit, ~0: no tile
-    float *s_lut = reinterpret_cast<float *>(tile_xy + HRT_SP_MAXG);     // the u8 -> float tables (512 floats)
+    SpUnit *const U = reinterpret_cast<SpUnit *>(&SH + 1);                // the two work units in flight
+    uint32_t *tile_xy = reinterpret_cast<uint32_t *>(U + HRT_SP_UNITS);              // [unit slot][tile]: x0 | y0 << 16, ~0: no such tile
+    float *s_lut = reinterpret_cast<float *>(tile_xy + HRT_SP_UNITS * HRT_SP_MAXG);  // the u8 -> float tables (512 floats)
     float4 *s_tabs = reinterpret_cast<float4 *>(s_lut + 512);            // 16-byte aligned: every size above is a multiple of 16
     CtxT<EXACT, true> cx;
     cx.S = (cscene)R.scene;
@@ -258,14 +278,18 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         C0.cQ[0][0] = C0.cQ[0][1] = 0;
         for (int k = 0; k < 4; ++k) C0.cQ[1 + k][0] = C0.cQ[1 + k][1] = 0;
         C0.cQ[5][0] = HRT_SP_QCAP; C0.cQ[5][1] = 0;
-        C0.parity = 1; C0.cycles = 0; C0.done = 0; C0.arrive = 0; C0.ready = 0; C0.cursor = 0; C0.ngen = 0; C0.gen_n0 = 0;
-        if (tid == 0) { SH.gen_next = 0; SH.gen_total = 0; SH.tile = 0; SH.abort = 0; }
+        C0.parity = 1; C0.done = 0; C0.arrive = 0; C0.ready = 0; C0.cursor = 0; C0.ngen = 0; C0.gen_n0 = 0; C0.gen_slot = 0; C0.gen_s0 = 0;
+        C0.red_slot = HRT_SP_UNITS; C0.red_j = 0; C0.red_s0 = 0; C0.red_ns = 0; C0.more = 1;
+        if (tid == 0) {
+            SH.lock = 0; SH.cur = 0; SH.tiles_done = 0; SH.abort = 0; SH.stall = 0;
+            for (int k = 0; k < HRT_SP_UNITS; ++k) { U[k].state = SP_U_FREE; U[k].j = 0; U[k].s0 = 0; U[k].ns = 0; U[k].gen_next = 0; U[k].gen_total = 0; U[k].outstanding = 0; }
+        }
     }
     for (uint32_t i = tid; i < HRT_SP_POOL; i += HRT_SP_WG)  // every slot free, in its stream's free queue (parity 0)
         q_all[(i / HRT_SP_QCAP) * (HRT_SP_NQ * HRT_SP_QCAP) + (2 * 3 + 0) * HRT_SP_QCAP + (i % HRT_SP_QCAP)] = (uint16_t)i;
     const bool has_mesh = cx.S->n_meshes != 0u;
     const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
-    float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNIT * 3u);
+    float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNITS * HRT_SP_UNIT * 3u);  // one part per unit slot
     const uint32_t glog = R.sp_group_log2, G = 1u << glog, upix = 64u << glog;  // tiles and pixels per unit
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
@@ -288,389 +312,462 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     unsigned long long dbg_class[6] = {0, 0, 0, 0, 0, 0};  // clocks in T, mesh-hit, sphere-hit, square-hit, miss, G chunks
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
 #endif
-    for (;;) {  // tiles
-        __syncthreads();
-        if (tid == 0) SH.tile = atomicAdd(R.tile_counter, G);
-        __syncthreads();
-        const uint32_t j = SP_UNI(SH.tile);  // first tile slot of the unit
-        if (j >= R.tiles_owned) break;  // finite queue: every workgroup gets here
-        if (tid < G) {
-            uint32_t xy = 0xFFFFFFFFu;
-            if (j + tid < R.tiles_owned) {
-                const uint32_t tile = R.rank + (j + tid) * R.world;
-                xy = ((tile % R.tiles_x) * 8u) | (((tile / R.tiles_x) * 8u) << 16);
-            }
-            tile_xy[tid] = xy;
-        }
-        for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {
-            float start = 0.f;
-            // progressive mode: continue the running sums of samples [0, s0) (tiles beyond the last one: never read back)
-            if (R.accumulate && j + i / 192u < R.tiles_owned) start = R.out_tiles[(size_t)j * 192u + i];
-            L.run[i] = start;
-        }
-
-        const uint32_t per_fold = min((uint32_t)HRT_SP_SCHUNK, (uint32_t)HRT_SP_UNIT / upix);  // samples per pixel between folds
-        for (uint32_t s0 = 0; s0 < R.spp; s0 += per_fold) {  // sample chunks of the unit
-            const uint32_t ns = min(per_fold, R.spp - s0);
-            __syncthreads();
-            // ---- the scheduler of one fold: HRT_SP_STREAMS streams of cycles, no barrier inside.
-            // A stream's cycle k: its control block (queue fills, new paths) is valid once ready == k; the waves pull its chunks
-            // from one cursor; a wave that finds none left waits for its own stores, ARRIVES (arrive += 1) and moves to the other
-            // stream.  The wave whose arrival completes the cycle (arrive == waves x k) runs the serial section -- it hands out
-            // new paths, swaps the queue buffers, carries the unused free slots over -- and publishes ready = k + 1.  Waves visit
-            // the streams in the fixed order A1 B1 A2 B2 ...; a stage only ever waits for all waves to have passed the previous
-            // stage of the same stream, so there is no cyclic wait.  Every wait is bounded (abort -> HRT_ERR_DEVICE on the host).
-            auto serial_section = [&](SpCtl &C, uint16_t *qs) {  // one whole wave; control values by lane 0
-                const uint32_t par = SP_UNI(C.parity) ^ 1u;  // the buffers the finished cycle appended to become the input
-                const uint32_t free_in = SP_UNI(C.cQ[5][par]);
+    // ---- the scheduler: HRT_SP_STREAMS streams of cycles over a PIPELINE of work units, no barrier anywhere inside.
+    // A stream's cycle k: its control block (queue fills, new paths, a reduction to run) is valid once ready == k; the waves pull
+    // its chunks from one cursor; a wave that finds none left waits for its own stores, ARRIVES (arrive += 1) and moves to the
+    // other stream.  The wave whose arrival completes the cycle (arrive == waves x k) runs the serial section -- unit bookkeeping,
+    // new paths, queue buffer swap, unused free slots -- and publishes ready = k + 1.  Waves visit the streams in the fixed order
+    // A1 B1 A2 B2 ...; a stage only ever waits for all waves to have passed the previous stage of the same stream, so there is no
+    // cyclic wait.  Every wait is bounded (abort -> HRT_ERR_DEVICE on the host).
+    //
+    // WORK UNITS.  A unit is G tiles x 64 pixels x the samples of one fold (<= HRT_SP_UNIT paths, its own half of the sample
+    // scratch).  HRT_SP_UNITS are in flight: while the paths of one DRAIN (every path started, the long ones still bouncing), new paths
+    // come from the other, so the pool stays full.  (With one unit at a time a quarter of the cycles ran a draining, half-empty
+    // pool.)  When a unit's last path has finished, the next cycle of whichever stream notices carries its REDUCTION as ordinary
+    // chunks: 64 (pixel, channel) columns each, the fold's samples added in sample order onto the running sums (main.cpp:193),
+    // which live in out_tiles between folds; the last fold leaves the mean (main.cpp:195).  A path knows its unit slot (the two top
+    // bits of its number).
+    const uint32_t per_fold = min((uint32_t)HRT_SP_SCHUNK, (uint32_t)HRT_SP_UNIT / upix);  // samples per pixel of one fold
+    auto serial_section = [&](SpCtl &C, uint16_t *qs) {  // one whole wave; control values by lane 0
+        const uint32_t par = SP_UNI(C.parity) ^ 1u;  // the buffers the finished cycle appended to become the input
+        const uint32_t free_in = SP_UNI(C.cQ[5][par]);
 #if HRT_SP_DEFER
-                const uint32_t want = free_in & ~63u;  // whole chunks of new paths only (the last paths of the fold come as they are)
+        const uint32_t want = free_in & ~63u;  // whole chunks of new paths only (the last paths of a fold come as they are)
 #else
-                const uint32_t want = free_in;
+        const uint32_t want = free_in;
 #endif
-                uint32_t old = 0;
-                if (lane == 0) old = atomicAdd(&SH.gen_next, want);
-                old = SP_UNI(old);
-                const uint32_t total_paths = SP_UNI(SH.gen_total);
-                const uint32_t ngen = old >= total_paths ? 0u : min(want, total_paths - old);
-                uint16_t *qFi = qs + (2 * 3 + par) * HRT_SP_QCAP, *qFo = qs + (2 * 3 + (par ^ 1u)) * HRT_SP_QCAP;
-                for (uint32_t i = lane; i < free_in - ngen; i += 64u) qFo[i] = qFi[ngen + i];  // carry unused free slots
-                // While the fold still has paths to start, a queue's last PARTIAL chunk waits for the next cycle (it moves to the front
-                // of the output queue, so the oldest entries go first): the paths are independent and the fold is ordered, so when a
-                // path is advanced changes nothing -- and the chunks that do run have all 64 lanes filled.  Once every path of the
-                // fold has been started, everything runs (the stream drains).
-                const bool defer = HRT_SP_DEFER && old + ngen < total_paths;
-                const uint32_t cT = SP_UNI(C.cQ[0][par]), rT = defer ? (cT & 63u) : 0u;
-                if (lane < rT) qs[(2 * 0 + (par ^ 1u)) * HRT_SP_QCAP + lane] = qs[(2 * 0 + par) * HRT_SP_QCAP + cT - rT + lane];
-                uint32_t cKv[4], rK[4], waiting = cT;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cKv[k] = SP_UNI(C.cQ[1 + k][par]);
-                    rK[k] = defer ? (cKv[k] & 63u) : 0u;
-                    waiting += cKv[k];
-                    const int which = (k == 1 || k == 2) ? 1 : 2;  // the addressing of sp_push_hit: kinds 1 and 0 from the front, 2 and 3 from the back
-                    const bool back = !(k == 1 || k == 0);
-                    const uint16_t *qi = qs + (2 * which + par) * HRT_SP_QCAP;
-                    uint16_t *qo = qs + (2 * which + (par ^ 1u)) * HRT_SP_QCAP;
-                    if (lane < rK[k]) {
-                        const uint32_t e = cKv[k] - rK[k] + lane;
-                        qo[back ? (uint32_t)HRT_SP_QCAP - 1u - lane : lane] = qi[back ? (uint32_t)HRT_SP_QCAP - 1u - e : e];
-                    }
+        if (lane == 0) {  // unit bookkeeping under the workgroup's lock: the two streams' serial sections can run at the same time
+            uint32_t spins = 0;
+            while (atomicCAS(&SH.lock, 0u, 1u) != 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {  // the holder runs a few dozen LDS operations and one global atomic
+                    if (R.stamps) { __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); R.stamps[14] = 1; }
+                    __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
                 }
-                if (lane == 0) {
+            }
+            bool progress = false;
+            // 1. the reduction this stream ran in the cycle that has just ended is complete: the unit's next fold, or a free slot
+            const uint32_t rs = C.red_slot;
+            if (rs < HRT_SP_UNITS) {
+                SpUnit &u = U[rs];
+                const uint32_t s_next = u.s0 + u.ns;
+                if (s_next < R.spp) {
+                    u.s0 = s_next; u.ns = min(per_fold, R.spp - s_next); u.gen_next = 0; u.gen_total = upix * u.ns; u.state = SP_U_READY;
+                } else {
+                    u.state = SP_U_FREE;
+                }
+                progress = true;
+            }
+            // 2. a unit whose every path has started and finished is reduced in the cycle now being prepared
+            uint32_t red = HRT_SP_UNITS;
+            for (uint32_t k = 0; k < HRT_SP_UNITS; ++k)
+                if (red == HRT_SP_UNITS && U[k].state == SP_U_DRAINING && __hip_atomic_load(&U[k].outstanding, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                    red = k;
+                    U[k].state = SP_U_REDUCING;
+                }
+            C.red_slot = red;
+            if (red < HRT_SP_UNITS) { C.red_j = U[red].j; C.red_s0 = U[red].s0; C.red_ns = U[red].ns; }
+            // 3. new paths: from the unit that is generating, else the next fold that is ready, else a new unit off the tile queue
+            uint32_t ngen = 0, n0 = 0, gs = 0;
+            if (want != 0u) {
+                uint32_t cur = SH.cur;
+                if (U[cur].state != SP_U_GENERATING) {
+                    cur = HRT_SP_UNITS;
+                    for (uint32_t k = 0; k < HRT_SP_UNITS; ++k)
+                        if (cur == HRT_SP_UNITS && U[k].state == SP_U_READY) cur = k;
+                    if (cur == HRT_SP_UNITS && SH.tiles_done == 0u)
+                        for (uint32_t k = 0; k < HRT_SP_UNITS; ++k)
+                            if (cur == HRT_SP_UNITS && U[k].state == SP_U_FREE) {
+                                const uint32_t j = atomicAdd(R.tile_counter, G);
+                                if (j >= R.tiles_owned) { SH.tiles_done = 1u; break; }  // finite queue
+                                SpUnit &u = U[k];
+                                u.j = j; u.s0 = 0; u.ns = min(per_fold, R.spp); u.gen_next = 0; u.gen_total = upix * u.ns;
+                                __hip_atomic_store(&u.outstanding, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                for (uint32_t t = 0; t < G; ++t) {
+                                    uint32_t xy = 0xFFFFFFFFu;
+                                    if (j + t < R.tiles_owned) {
+                                        const uint32_t tile = R.rank + (j + t) * R.world;
+                                        xy = ((tile % R.tiles_x) * 8u) | (((tile / R.tiles_x) * 8u) << 16);
+                                    }
+                                    tile_xy[k * HRT_SP_MAXG + t] = xy;
+                                }
+                                cur = k;
+                                progress = true;
+                            }
+                    if (cur < HRT_SP_UNITS) { U[cur].state = SP_U_GENERATING; SH.cur = cur; }
+                }
+                if (cur < HRT_SP_UNITS) {
+                    SpUnit &u = U[cur];
+                    n0 = u.gen_next;
+                    ngen = min(want, u.gen_total - n0);
+                    u.gen_next = n0 + ngen;
+                    atomicAdd(&u.outstanding, ngen);
+                    if (u.gen_next == u.gen_total) u.state = SP_U_DRAINING;
+                    gs = cur;
+                }
+            }
+            bool generating = false, idle = SH.tiles_done != 0u;  // generating: paths can be started without anything having to finish first
+            for (uint32_t k = 0; k < HRT_SP_UNITS; ++k) {
+                generating = generating || U[k].state == SP_U_READY || U[k].state == SP_U_GENERATING || (U[k].state == SP_U_FREE && SH.tiles_done == 0u);
+                idle = idle && U[k].state == SP_U_FREE;
+            }
+            C.ngen = ngen; C.gen_n0 = n0; C.gen_slot = gs; C.gen_s0 = U[gs].s0;
+            C.more = generating ? 1u : 0u;
+            C.done = idle ? 1u : 0u;  // (and nothing waiting in this stream: checked below)
+            if (progress) SH.stall = 0;
+            else if (++SH.stall > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
+                // The frame is lost: flag it for the host (hrt_check_last_launch / hrt_render return HRT_ERR_DEVICE) and take
+                // the whole workgroup out of the kernel.  The other workgroups finish their tiles.
+                if (R.stamps) {
+                    __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    R.stamps[14] = 2;  // diagnostic: which bound, and the unit slots at that moment
+                    for (uint32_t k = 0; k < HRT_SP_UNITS; ++k) R.stamps[8 + k] = ((unsigned long long)U[k].state << 48) | ((unsigned long long)U[k].outstanding << 24) | U[k].gen_next;
+                    R.stamps[12] = ((unsigned long long)SH.tiles_done << 32) | SH.cur; R.stamps[13] = ((unsigned long long)want << 32) | C.cQ[0][par];
+                }
+                __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __hip_atomic_store(&SH.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t ngen = SP_UNI(C.ngen);
+        uint16_t *qFi = qs + (2 * 3 + par) * HRT_SP_QCAP, *qFo = qs + (2 * 3 + (par ^ 1u)) * HRT_SP_QCAP;
+        for (uint32_t i = lane; i < free_in - ngen; i += 64u) qFo[i] = qFi[ngen + i];  // carry unused free slots
+        // While new paths can be started (a unit is generating, or a slot is free for the next tiles), a queue's last PARTIAL chunk
+        // waits for the next cycle (it moves to the front of the output queue, so the oldest entries go first): the paths are
+        // independent and every fold is ordered, so when a path is advanced changes nothing -- and the chunks that do run have
+        // all 64 lanes filled.  When every unit slot is draining, new paths wait for old ones to finish: then everything runs.
+        const bool defer = HRT_SP_DEFER && SP_UNI(C.more) != 0u;
+        const uint32_t cT = SP_UNI(C.cQ[0][par]), rT = defer ? (cT & 63u) : 0u;
+        if (lane < rT) qs[(2 * 0 + (par ^ 1u)) * HRT_SP_QCAP + lane] = qs[(2 * 0 + par) * HRT_SP_QCAP + cT - rT + lane];
+        uint32_t cKv[4], rK[4], waiting = cT;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { C.cQ[1 + k][par] = cKv[k] - rK[k]; C.cQ[1 + k][par ^ 1u] = rK[k]; }
-                    C.cQ[0][par] = cT - rT;
-                    C.cQ[0][par ^ 1u] = rT;
-                    C.cQ[5][par ^ 1u] = free_in - ngen;  // the unused free slots carry over, freed slots are appended after them
-                    C.ngen = ngen; C.gen_n0 = old; C.cursor = 0; C.parity = par;
-                    C.done = (ngen == 0u && waiting == 0u) ? 1u : 0u;  // nothing in flight and nothing left to start: the stream has drained
-                    if (++C.cycles > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
-                        // The frame is lost: flag it for the host (hrt_check_last_launch / hrt_render return HRT_ERR_DEVICE) and take
-                        // the whole workgroup out of the kernel -- its queues and pool hold paths in flight, so it must not start
-                        // another unit from that state.  The other workgroups finish their tiles.
-                        if (R.stamps) __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int k = 0; k < 4; ++k) {
+            cKv[k] = SP_UNI(C.cQ[1 + k][par]);
+            rK[k] = defer ? (cKv[k] & 63u) : 0u;
+            waiting += cKv[k];
+            const int which = (k == 1 || k == 2) ? 1 : 2;  // the addressing of sp_push_all: kinds 1 and 0 from the front, 2 and 3 from the back
+            const bool back = !(k == 1 || k == 0);
+            const uint16_t *qi = qs + (2 * which + par) * HRT_SP_QCAP;
+            uint16_t *qo = qs + (2 * which + (par ^ 1u)) * HRT_SP_QCAP;
+            if (lane < rK[k]) {
+                const uint32_t e = cKv[k] - rK[k] + lane;
+                qo[back ? (uint32_t)HRT_SP_QCAP - 1u - lane : lane] = qi[back ? (uint32_t)HRT_SP_QCAP - 1u - e : e];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { C.cQ[1 + k][par] = cKv[k] - rK[k]; C.cQ[1 + k][par ^ 1u] = rK[k]; }
+            C.cQ[0][par] = cT - rT;
+            C.cQ[0][par ^ 1u] = rT;
+            C.cQ[5][par ^ 1u] = free_in - ngen;  // the unused free slots carry over, freed slots are appended after them
+            C.cursor = 0; C.parity = par;
+            // the stream ends when the launch has: no tile left, both unit slots free -- then nothing is in flight anywhere
+            C.done = (C.done != 0u && ngen == 0u && waiting == 0u && C.red_slot == HRT_SP_UNITS) ? 1u : 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // control block and free list are in LDS before the cycle is announced
+        if (lane == 0) __hip_atomic_store(&C.ready, C.ready + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    __syncthreads();  // tables, queues and control blocks are set up
+    if (tid < 64u)    // wave 0 opens the launch: cycle 1 of every stream (the first one takes the first unit off the tile queue)
+        for (uint32_t st = 0; st < HRT_SP_STREAMS; ++st) serial_section(L.ctl[st], q_all + st * (HRT_SP_NQ * HRT_SP_QCAP));
+    __syncthreads();
+    uint32_t fin[HRT_SP_UNITS];  // paths of each unit slot this wave has finished since it last arrived
+    for (int k = 0; k < HRT_SP_UNITS; ++k) fin[k] = 0u;
+
+    uint32_t kcyc[HRT_SP_STREAMS], fin_mask = 0u;
+    for (uint32_t st = 0; st < HRT_SP_STREAMS; ++st) kcyc[st] = 1u;
+    for (uint32_t round = 0;; ++round) {  // stages A1 B1 A2 B2 ... of this wave
+        const uint32_t st = HRT_SP_STREAMS == 1 ? 0u : (round & 1u);
+        if (fin_mask == (1u << HRT_SP_STREAMS) - 1u) break;
+        if (fin_mask & (1u << st)) continue;
+        SpCtl &C = L.ctl[st];
+        L.q = q_all + st * (HRT_SP_NQ * HRT_SP_QCAP);
+        {   // wait for the control block of this stage (normally there already)
+#ifdef HRT_SP_DEBUG
+            const unsigned long long dbg_q0 = __builtin_readcyclecounter();
+#endif
+            uint32_t spins = 0, aborted = 0;
+            while (SP_UNI(__hip_atomic_load(&C.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kcyc[st]) {
+                __builtin_amdgcn_s_sleep(8);
+                aborted = SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (aborted) break;
+                if (++spins > (1u << 24)) {  // seconds: nothing legitimate takes that long
+                    if (lane == 0) {
+                        if (R.stamps) { __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); R.stamps[14] = 3; }
                         __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // control block and free list are in LDS before the cycle is announced
-                if (lane == 0) __hip_atomic_store(&C.ready, C.ready + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            if (tid < 64u) {  // wave 0 opens the fold: cycle 1 of every stream
-                if (lane == 0) { SH.gen_next = 0; SH.gen_total = upix * ns; }
-                for (uint32_t st = 0; st < HRT_SP_STREAMS; ++st) {
-                    SpCtl &C = L.ctl[st];
-                    if (lane == 0) { C.cycles = 0; C.arrive = 0; C.ready = 0; }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // between folds every path is free again: the free list of the last input parity holds every slot of the stream
-                    serial_section(C, q_all + st * (HRT_SP_NQ * HRT_SP_QCAP));
+                    aborted = 1u;
+                    break;
                 }
             }
-            __syncthreads();
-            uint32_t kcyc[HRT_SP_STREAMS], fin_mask = 0u;
-            for (uint32_t st = 0; st < HRT_SP_STREAMS; ++st) kcyc[st] = 1u;
-            for (uint32_t round = 0;; ++round) {  // stages A1 B1 A2 B2 ... of this wave
-                const uint32_t st = HRT_SP_STREAMS == 1 ? 0u : (round & 1u);
-                if (fin_mask == (1u << HRT_SP_STREAMS) - 1u) break;
-                if (fin_mask & (1u << st)) continue;
-                SpCtl &C = L.ctl[st];
-                L.q = q_all + st * (HRT_SP_NQ * HRT_SP_QCAP);
-                {   // wait for the control block of this stage (normally there already)
 #ifdef HRT_SP_DEBUG
-                    const unsigned long long dbg_q0 = __builtin_readcyclecounter();
+            dbg_wait += __builtin_readcyclecounter() - dbg_q0;
 #endif
-                    uint32_t spins = 0, aborted = 0;
-                    while (SP_UNI(__hip_atomic_load(&C.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kcyc[st]) {
-                        __builtin_amdgcn_s_sleep(8);
-                        aborted = SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        if (aborted) break;
-                        if (++spins > (1u << 24)) {  // seconds: nothing legitimate takes that long
-                            if (lane == 0) {
-                                if (R.stamps) __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-                            aborted = 1u;
-                            break;
-                        }
-                    }
+            if (aborted || SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+        }
+        if (SP_UNI(C.done)) { fin_mask |= 1u << st; continue; }
+        const uint32_t parity = SP_UNI(C.parity);
+        const uint32_t ngen = SP_UNI(C.ngen), n0 = SP_UNI(C.gen_n0), gs = SP_UNI(C.gen_slot), s0 = SP_UNI(C.gen_s0);
+        const uint32_t red = SP_UNI(C.red_slot), nR = red < HRT_SP_UNITS ? (G * 192u + 63u) >> 6 : 0u;  // reduction chunks: 64 columns each
+        const uint32_t cTin = SP_UNI(C.cQ[0][parity]);
+        const uint32_t cK0 = SP_UNI(C.cQ[1][parity]), cK1 = SP_UNI(C.cQ[2][parity]), cK2 = SP_UNI(C.cQ[3][parity]),
+                       cK3 = SP_UNI(C.cQ[4][parity]);
+        // chunk ranges of this cycle: T (longest) first, then mesh, sphere, square hits, misses, new paths last
+        const uint32_t nT = HRT_SP_THALF ? (cTin + 31u) >> 5 : (cTin + 63u) >> 6, e3 = nT + ((cK3 + 63u) >> 6), e1 = e3 + ((cK1 + 63u) >> 6),
+                       e2 = e1 + ((cK2 + 63u) >> 6), e0 = e2 + ((cK0 + 63u) >> 6), nG = (ngen + 63u) >> 6, total = e0 + nG;
+        uint16_t *qTi = spq(L, 0, parity);
+        uint16_t *qAi = spq(L, 1, parity), *qBi = spq(L, 2, parity);
+        uint16_t *qFi = spq(L, 3, parity);
 #ifdef HRT_SP_DEBUG
-                    dbg_wait += __builtin_readcyclecounter() - dbg_q0;
-#endif
-                    if (aborted || SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
-                }
-                if (SP_UNI(C.done)) { fin_mask |= 1u << st; continue; }
-                const uint32_t parity = SP_UNI(C.parity);
-                const uint32_t ngen = SP_UNI(C.ngen), n0 = SP_UNI(C.gen_n0);
-                const uint32_t cTin = SP_UNI(C.cQ[0][parity]);
-                const uint32_t cK0 = SP_UNI(C.cQ[1][parity]), cK1 = SP_UNI(C.cQ[2][parity]), cK2 = SP_UNI(C.cQ[3][parity]),
-                               cK3 = SP_UNI(C.cQ[4][parity]);
-                // chunk ranges of this cycle: T (longest) first, then mesh, sphere, square hits, misses, new paths last
-                const uint32_t nT = HRT_SP_THALF ? (cTin + 31u) >> 5 : (cTin + 63u) >> 6, e3 = nT + ((cK3 + 63u) >> 6), e1 = e3 + ((cK1 + 63u) >> 6),
-                               e2 = e1 + ((cK2 + 63u) >> 6), e0 = e2 + ((cK0 + 63u) >> 6), nG = (ngen + 63u) >> 6, total = e0 + nG;
-                uint16_t *qTi = spq(L, 0, parity);
-                uint16_t *qAi = spq(L, 1, parity), *qBi = spq(L, 2, parity);
-                uint16_t *qFi = spq(L, 3, parity);
-#ifdef HRT_SP_DEBUG
-                const unsigned long long dbg_w0 = __builtin_readcyclecounter();
-                ++dbg_cycles;
+        const unsigned long long dbg_w0 = __builtin_readcyclecounter();
+        ++dbg_cycles;
 #endif
 
-                for (;;) {  // chunks of this cycle: T first (longest), then S, then G
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(&C.cursor, 1u);
-                    c = SP_UNI(c);
-                    if (c >= total) break;
-#ifdef HRT_SP_DEBUG
-                    ++dbg_chunks;
-                    const unsigned long long dbg_c0 = __builtin_readcyclecounter();
-                    const uint32_t dbg_k = c < nT ? 0u : (c < e3 ? 1u : (c < e1 ? 2u : (c < e2 ? 3u : (c < e0 ? 4u : 5u))));
-#endif
-                    if (c < nT) {
-                        // ---------------- T: mesh walk
-                        const uint32_t e = HRT_SP_THALF ? c * 32u + lane : c * 64u + lane;
-                        const bool act = e < cTin && (!HRT_SP_THALF || lane < 32u);
-                        uint32_t slot = 0, kind = 0, pm = 0, ref_in = HRT_KD_NIL, pm_before = 0;
-                        bool walked = false;
-                        Ray ray;
-                        ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
-                        Hit h;
-                        h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
-                        Walk w;
-                        w.ref = HRT_KD_NIL; w.t_entry = 0.f; w.kk = 0xFFFFu; w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
-                        SEG_START(HRT_SP_SEG_KIND == 2);
-                        if (act) {
-                            slot = qTi[e] & (HRT_SP_POOL - 1u);
-                            uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g3 = sp_ld4(L, 3, slot),
-                                  g4 = sp_ld4(L, 4, slot);
-#if HRT_SP_GLOBAL
-                            asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g3), SP_PIN1(g4));
-#endif
-                            sp_unpack_ray_hit(g0, g1, g2, ray, h, pm);  // (the mesh walk does not read ray.time)
-                            pm_before = pm;
-                            w.ref = g3.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
-                            ref_in = w.ref;
-                            w.best_tri = g4.x; w.bu = __uint_as_float(g4.y); w.bv = __uint_as_float(g4.z);
-                        }
-#ifdef HRT_SP_SEG
-                        asm volatile("" : "+v"(ray.o.x), "+v"(w.t_entry), "+v"(h.t));
-#endif
-                        SEG(0);  // T: record loaded
-                        if (act) {
-                            walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
-                        }
-                        SEG(1);  // T: walk
-                        if (act) {
-                            const uint32_t pm_in = pm_before;
-                            if (pm != pm_in) {  // a mesh was finished: the best hit may have changed (g1 also carries d.y, d.z: rewritten as read)
-                                sp_st4(L, 1, slot, make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(h.t), (h.kind << 28) | h.index));
-                                sp_st4(L, 2, slot, make_uint4(__float_as_uint(h.a0), __float_as_uint(h.a1), h.tri, pm));
-                            }
-                            if (!walked) {  // the state of the walk in progress
-                                sp_st4(L, 3, slot, make_uint4(w.ref, __float_as_uint(w.t_entry), w.kk, __float_as_uint(w.best_t)));
-                                sp_st4(L, 4, slot, make_uint4(w.best_tri, __float_as_uint(w.bu), __float_as_uint(w.bv), 0u));
-                            } else if (ref_in != HRT_KD_NIL) {
-                                spu(L, SP_WREF, slot) = HRT_KD_NIL;  // invariant: SP_WREF is NIL whenever the path is not in a T queue
-                            }
-                            kind = h.kind;
-                        }
-                        // unfinished: joins the next cycle's T chunks; finished: the closest-hit queue of its kind
-                        sp_push_all(L, C, parity ^ 1u, !act ? SP_TO_NONE : (walked ? 1u + kind : 0u), slot);
-                        SEG(2);  // T: stores + appends
-#ifdef HRT_SP_SEG
-                        if (seg_on) { seg[7] += 1; seg[6] += (unsigned long long)__popcll(__ballot(act)); seg[5] += (unsigned long long)__popcll(__ballot(act && walked)); }
-#endif
-                    } else {
-                        // ---------------- S (shade + scatter, then next prims) and G (camera ray, then prims)
-                        const bool is_gen = c >= e0;
-                        // which closest-hit queue this chunk drains: its entries, its fill, and where entry e sits
-                        const uint32_t first = is_gen ? e0 : (c < e3 ? nT : (c < e1 ? e3 : (c < e2 ? e1 : e2)));
-                        const uint32_t fill = is_gen ? ngen : (c < e3 ? cK3 : (c < e1 ? cK1 : (c < e2 ? cK2 : cK0)));
-                        const bool from_back = !is_gen && (c < e3 || (c >= e1 && c < e2));  // mesh and square hits grow from the end
-                        const uint16_t *qHi = (c < e3 || c >= e2) ? qBi : qAi;
-                        const uint32_t e = (c - first) * 64u + lane;
-                        const bool act = e < fill;
-                        uint32_t slot = 0, kind = 0;
-                        bool trace = false, freed = false;  // trace: the path has a new ray to intersect
-                        SEG_START(HRT_SP_SEG_KIND == 1 && !is_gen && c >= e1 && c < e2);  // square-hit chunks
-                        Ray ray;
-                        ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
-                        if (act && is_gen) {
-                            slot = qFi[e] & (HRT_SP_POOL - 1u);
-                            const uint32_t n = n0 + e;  // path n of the unit = (sample n / upix, pixel n % upix)
-                            const uint32_t q = n & (upix - 1u), s = s0 + (n >> (6u + glog));
-                            const uint32_t p = q & 63u, txy = tile_xy[q >> 6];
-                            const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
-                            if (txy != 0xFFFFFFFFu && px < R.w && py < R.h) {
-                                Rng rng;
-                                rng.start(R.seed_lo, R.seed_hi, py * R.w + px, R.s0 + s);
-                                const float u = ((float)px + rng.next()) / (float)R.w;
-                                const float v = ((float)py + rng.next()) / (float)R.h;
-                                const float tm = rng.next();
-                                ray = camera_ray<EXACT>(cam, u, v, tm);
-                                sp_st4(L, 5, slot, make_uint4(__float_as_uint(tm), rng.k0, rng.k1, n));
-                                sp_st4(L, 6, slot, sp_pack(1.f, 1.f, 1.f, 0.f));                                  // throughput 1, radiance 0
-                                sp_st4(L, 7, slot, make_uint4(0u, 0u, rng.i, 6u));                               // MAXBOUNCES
-                                trace = true;
-                            } else {  // pixel outside a ragged image: the sample is zero, the slot stays free
-                                float *o = scratch + (size_t)n * 3u;
-                                o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
-                                freed = true;
-                            }
-                        } else if (act) {
-                            slot = qHi[from_back ? (uint32_t)HRT_SP_QCAP - 1u - e : e] & (HRT_SP_POOL - 1u);
-                            uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g5 = sp_ld4(L, 5, slot),
-                                  g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
-#if HRT_SP_GLOBAL
-                            asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g5), SP_PIN1(g6), SP_PIN1(g7));
-#endif
-                            Hit h;
-                            uint32_t pm_unused;
-                            sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
-                            ray.time = __uint_as_float(g5.x);
-                            f3 thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
-                            f3 rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
-                            int remaining = (int)g7.w;
-#ifdef HRT_SP_SEG
-                            asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
-#endif
-                            SEG(0);  // record loaded
-                            bool ended;
-                            if (h.kind == 0u) {
-                                rad = rad + thr * sky(cx, ray.d, remaining);
-                                ended = true;
-                            } else {
-                                Rng rng;
-                                rng.k0 = g5.y; rng.k1 = g5.z; rng.i = g7.z;
-                                const Surface sf = shade(cx, ray, h);
-                                SEG(1);  // shade: material rows, texel, normal map
-                                f3 direct = mk(0.f, 0.f, 0.f);
-                                if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
-                                rad = rad + thr * (direct + sf.emission);
-                                thr = thr * sf.albedo;
-                                scatter(sf, ray, rng);
-                                SEG(2);  // scatter
-                                --remaining;
-                                ended = (remaining == 0);
-                                if (!ended) {
-                                    sp_st4(L, 6, slot, sp_pack(thr.x, thr.y, thr.z, rad.x));
-                                    sp_st4(L, 7, slot, make_uint4(__float_as_uint(rad.y), __float_as_uint(rad.z), rng.i, (uint32_t)remaining));
-                                    trace = true;
-                                }
-                            }
-                            if (ended) {  // Scene.h:348: the sample's colour, parked until the ordered fold
-                                const uint32_t n = min(g5.w, (uint32_t)HRT_SP_UNIT - 1u);  // the path's number; stays inside the scratch
-                                float *o = scratch + (size_t)n * 3u;
-                                o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
-                                freed = true;
-                            }
-                        }
-                        // spheres + squares + mesh gates for every lane of the chunk that has a new ray
-                        bool to_mesh = false;
-                        SEG(3);  // state written back / sample stored
-                        Hit hn;
-                        hn.kind = 0; hn.index = 0; hn.t = HRT_FLT_MAX; hn.tri = 0; hn.a0 = 0.f; hn.a1 = 0.f;
-                        uint32_t pmn = 0;
-                        if (trace) {
-                            hn = prims_hit(cx, ray);
-                            SEG(4);  // spheres + squares
-                            pmn = has_mesh ? mesh_gates(cx, ray) : 0u;
-                            SEG(5);  // mesh gates
-                        }
-                        if (trace) {
-                            sp_store_ray_hit(L, slot, ray, hn, pmn);
-                            if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
-                            to_mesh = pmn != 0u;
-                            kind = hn.kind;
-                        }
-                        sp_push_all(L, C, parity ^ 1u, trace ? (to_mesh ? 0u : 1u + kind) : (freed ? 5u : SP_TO_NONE), slot);
-                        SEG(6);  // record stores + queue appends
-#ifdef HRT_SP_SEG
-                        if (seg_on) seg[7] += 1;
-#endif
+        for (;;) {  // chunks of this cycle: T first (longest), then S, then G
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&C.cursor, 1u);
+            c = SP_UNI(c);
+            if (c >= nR + total) break;
+            if (c < nR) {
+                // ---------------- R: 64 (pixel, channel) columns of a finished fold, its samples added in sample order (main.cpp:193)
+                // Plain loads: the scratch was written by waves of THIS workgroup (one CU), each of which waited for its stores
+                // (s_waitcnt vmcnt(0)) before the arrival that took the unit's count of paths in flight to zero; a CU's vector
+                // L1 is coherent with that CU's own stores (it is only other CUs' stores it never sees), which is also what the
+                // path pool's plain loads and stores rely on.
+                const uint32_t i = c * 64u + lane;  // pixel-of-unit * 3 + channel
+                const uint32_t rj = SP_UNI(C.red_j), rs0 = SP_UNI(C.red_s0), rns = SP_UNI(C.red_ns);
+                if (i < G * 192u && rj + i / 192u < R.tiles_owned) {
+                    float *out = R.out_tiles + (size_t)rj * 192u + i;
+                    // the running sum: samples [0, rs0) of this launch, on top of the earlier launches' in progressive mode
+                    float acc = (rs0 != 0u || R.accumulate) ? *out : 0.f;
+                    const float *col = scratch + (size_t)red * ((size_t)HRT_SP_UNIT * 3u) + i;
+                    const uint32_t stride = upix * 3u;
+                    uint32_t sm = 0;
+                    for (; sm + 8u <= rns; sm += 8u) {  // 8 loads in flight, added in sample order
+                        float v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = col[(size_t)(sm + k) * stride];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc += v[k];
                     }
-#ifdef HRT_SP_DEBUG
-                    dbg_class[dbg_k] += __builtin_readcyclecounter() - dbg_c0;
-#endif
+                    for (; sm < rns; ++sm) acc += col[(size_t)sm * stride];
+                    if (rs0 + rns >= R.spp) {  // the last fold: the pixel's value
+                        const uint32_t q = i / 3u, p = q & 63u, txy = tile_xy[red * HRT_SP_MAXG + (q >> 6)];
+                        const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
+                        if (!(px < R.w && py < R.h)) acc = 0.f;
+                        else if (!R.accumulate) acc = acc / (float)R.spp;  // main.cpp:195; progressive mode keeps the sum
+                    }
+                    *out = acc;
                 }
-#ifdef HRT_SP_DEBUG
-                dbg_work += __builtin_readcyclecounter() - dbg_w0;
-                if (ngen == 0u) { dbg_tail += __builtin_readcyclecounter() - dbg_w0; ++dbg_tail_cycles; }  // cycles of the drain: nothing left to start
-#endif
-                // this wave's part of the cycle is done: its records are in memory and its queue entries in LDS before it arrives
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                uint32_t arrived = 0;
-                if (lane == 0) arrived = __hip_atomic_fetch_add(&C.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                arrived = SP_UNI(arrived);
-#ifdef HRT_SP_DEBUG
-                const unsigned long long dbg_s0 = __builtin_readcyclecounter();
-#endif
-                if (arrived + 1u == (HRT_SP_WG / 64u) * kcyc[st]) serial_section(C, L.q);  // the last wave prepares the stream's next cycle
-#ifdef HRT_SP_DEBUG
-                dbg_serial += __builtin_readcyclecounter() - dbg_s0;
-#endif
-                ++kcyc[st];
+                continue;
             }
-            L.q = q_all;
+            c -= nR;
 #ifdef HRT_SP_DEBUG
-            const unsigned long long dbg_d0 = __builtin_readcyclecounter();
+            ++dbg_chunks;
+            const unsigned long long dbg_c0 = __builtin_readcyclecounter();
+            const uint32_t dbg_k = c < nT ? 0u : (c < e3 ? 1u : (c < e1 ? 2u : (c < e2 ? 3u : (c < e0 ? 4u : 5u))));
 #endif
-            __syncthreads();
-#ifdef HRT_SP_DEBUG
-            dbg_drain += __builtin_readcyclecounter() - dbg_d0;
+            if (c < nT) {
+                // ---------------- T: mesh walk
+                const uint32_t e = HRT_SP_THALF ? c * 32u + lane : c * 64u + lane;
+                const bool act = e < cTin && (!HRT_SP_THALF || lane < 32u);
+                uint32_t slot = 0, kind = 0, pm = 0, ref_in = HRT_KD_NIL, pm_before = 0;
+                bool walked = false;
+                Ray ray;
+                ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
+                Hit h;
+                h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
+                Walk w;
+                w.ref = HRT_KD_NIL; w.t_entry = 0.f; w.kk = 0xFFFFu; w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
+                SEG_START(HRT_SP_SEG_KIND == 2);
+                if (act) {
+                    slot = qTi[e] & (HRT_SP_POOL - 1u);
+                    uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g3 = sp_ld4(L, 3, slot),
+                          g4 = sp_ld4(L, 4, slot);
+#if HRT_SP_GLOBAL
+                    asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g3), SP_PIN1(g4));
 #endif
-            if (SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;  // uniform: read behind the barrier
-            // the fold has drained: its samples go into the pixel sums in sample order (main.cpp:193)
-            // Plain loads: the scratch was written by waves of THIS workgroup (one CU), every one of which passed the
-            // barrier above after its stores (s_waitcnt vmcnt(0) + s_barrier); a CU's vector L1 is coherent with that CU's
-            // own stores (it is only other CUs' stores it never sees), which is also what the path pool's plain loads and
-            // stores rely on.  (Round 1 put an agent-scope acquire here "against stale L1 lines"; an A/B without it is
-            // bit-identical on every kernel-form test at 1080p -- the hazard does not exist within one workgroup.)
-            for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {  // i = pixel-of-unit * 3 + channel
-                float acc = L.run[i];
-                const float *col = scratch + i;
-                const uint32_t stride = upix * 3u;
-                uint32_t s = 0;
-                for (; s + 8u <= ns; s += 8u) {  // 8 loads in flight, added in sample order (32 in flight: no faster, the fold is ~1 % of the launch)
-                    float v[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = col[(size_t)(s + k) * stride];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc += v[k];
+                    sp_unpack_ray_hit(g0, g1, g2, ray, h, pm);  // (the mesh walk does not read ray.time)
+                    pm_before = pm;
+                    w.ref = g3.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
+                    ref_in = w.ref;
+                    w.best_tri = g4.x; w.bu = __uint_as_float(g4.y); w.bv = __uint_as_float(g4.z);
                 }
-                for (; s < ns; ++s) acc += col[(size_t)s * stride];
-                L.run[i] = acc;
+#ifdef HRT_SP_SEG
+                asm volatile("" : "+v"(ray.o.x), "+v"(w.t_entry), "+v"(h.t));
+#endif
+                SEG(0);  // T: record loaded
+                if (act) {
+                    walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
+                }
+                SEG(1);  // T: walk
+                if (act) {
+                    const uint32_t pm_in = pm_before;
+                    if (pm != pm_in) {  // a mesh was finished: the best hit may have changed (g1 also carries d.y, d.z: rewritten as read)
+                        sp_st4(L, 1, slot, make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(h.t), (h.kind << 28) | h.index));
+                        sp_st4(L, 2, slot, make_uint4(__float_as_uint(h.a0), __float_as_uint(h.a1), h.tri, pm));
+                    }
+                    if (!walked) {  // the state of the walk in progress
+                        sp_st4(L, 3, slot, make_uint4(w.ref, __float_as_uint(w.t_entry), w.kk, __float_as_uint(w.best_t)));
+                        sp_st4(L, 4, slot, make_uint4(w.best_tri, __float_as_uint(w.bu), __float_as_uint(w.bv), 0u));
+                    } else if (ref_in != HRT_KD_NIL) {
+                        spu(L, SP_WREF, slot) = HRT_KD_NIL;  // invariant: SP_WREF is NIL whenever the path is not in a T queue
+                    }
+                    kind = h.kind;
+                }
+                // unfinished: joins the next cycle's T chunks; finished: the closest-hit queue of its kind
+                sp_push_all(L, C, parity ^ 1u, !act ? SP_TO_NONE : (walked ? 1u + kind : 0u), slot);
+                SEG(2);  // T: stores + appends
+#ifdef HRT_SP_SEG
+                if (seg_on) { seg[7] += 1; seg[6] += (unsigned long long)__popcll(__ballot(act)); seg[5] += (unsigned long long)__popcll(__ballot(act && walked)); }
+#endif
+            } else {
+                // ---------------- S (shade + scatter, then next prims) and G (camera ray, then prims)
+                const bool is_gen = c >= e0;
+                // which closest-hit queue this chunk drains: its entries, its fill, and where entry e sits
+                const uint32_t first = is_gen ? e0 : (c < e3 ? nT : (c < e1 ? e3 : (c < e2 ? e1 : e2)));
+                const uint32_t fill = is_gen ? ngen : (c < e3 ? cK3 : (c < e1 ? cK1 : (c < e2 ? cK2 : cK0)));
+                const bool from_back = !is_gen && (c < e3 || (c >= e1 && c < e2));  // mesh and square hits grow from the end
+                const uint16_t *qHi = (c < e3 || c >= e2) ? qBi : qAi;
+                const uint32_t e = (c - first) * 64u + lane;
+                const bool act = e < fill;
+                uint32_t slot = 0, kind = 0, fin_unit = 0;
+                bool trace = false, freed = false;  // trace: the path has a new ray to intersect; freed: its path has ended (unit fin_unit)
+                SEG_START(HRT_SP_SEG_KIND == 1 && !is_gen && c >= e1 && c < e2);  // square-hit chunks
+                Ray ray;
+                ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
+                if (act && is_gen) {
+                    slot = qFi[e] & (HRT_SP_POOL - 1u);
+                    const uint32_t n = n0 + e;  // path n of the unit = (sample n / upix, pixel n % upix)
+                    const uint32_t q = n & (upix - 1u), s = s0 + (n >> (6u + glog));
+                    const uint32_t p = q & 63u, txy = tile_xy[gs * HRT_SP_MAXG + (q >> 6)];
+                    const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
+                    if (txy != 0xFFFFFFFFu && px < R.w && py < R.h) {
+                        Rng rng;
+                        rng.start(R.seed_lo, R.seed_hi, py * R.w + px, R.s0 + s);
+                        const float u = ((float)px + rng.next()) / (float)R.w;
+                        const float v = ((float)py + rng.next()) / (float)R.h;
+                        const float tm = rng.next();
+                        ray = camera_ray<EXACT>(cam, u, v, tm);
+                        sp_st4(L, 5, slot, make_uint4(__float_as_uint(tm), rng.k0, rng.k1, n | (gs << 30)));
+                        sp_st4(L, 6, slot, sp_pack(1.f, 1.f, 1.f, 0.f));                                  // throughput 1, radiance 0
+                        sp_st4(L, 7, slot, make_uint4(0u, 0u, rng.i, 6u));                               // MAXBOUNCES
+                        trace = true;
+                    } else {  // pixel outside a ragged image: the sample is zero, the slot stays free
+                        float *o = scratch + (size_t)gs * ((size_t)HRT_SP_UNIT * 3u) + (size_t)n * 3u;
+                        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+                        freed = true;
+                        fin_unit = gs;
+                    }
+                } else if (act) {
+                    slot = qHi[from_back ? (uint32_t)HRT_SP_QCAP - 1u - e : e] & (HRT_SP_POOL - 1u);
+                    uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g5 = sp_ld4(L, 5, slot),
+                          g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
+#if HRT_SP_GLOBAL
+                    asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g5), SP_PIN1(g6), SP_PIN1(g7));
+#endif
+                    Hit h;
+                    uint32_t pm_unused;
+                    sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
+                    ray.time = __uint_as_float(g5.x);
+                    f3 thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
+                    f3 rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
+                    int remaining = (int)g7.w;
+#ifdef HRT_SP_SEG
+                    asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
+#endif
+                    SEG(0);  // record loaded
+                    bool ended;
+                    if (h.kind == 0u) {
+                        rad = rad + thr * sky(cx, ray.d, remaining);
+                        ended = true;
+                    } else {
+                        Rng rng;
+                        rng.k0 = g5.y; rng.k1 = g5.z; rng.i = g7.z;
+                        const Surface sf = shade(cx, ray, h);
+                        SEG(1);  // shade: material rows, texel, normal map
+                        f3 direct = mk(0.f, 0.f, 0.f);
+                        if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
+                        rad = rad + thr * (direct + sf.emission);
+                        thr = thr * sf.albedo;
+                        scatter(sf, ray, rng);
+                        SEG(2);  // scatter
+                        --remaining;
+                        ended = (remaining == 0);
+                        if (!ended) {
+                            sp_st4(L, 6, slot, sp_pack(thr.x, thr.y, thr.z, rad.x));
+                            sp_st4(L, 7, slot, make_uint4(__float_as_uint(rad.y), __float_as_uint(rad.z), rng.i, (uint32_t)remaining));
+                            trace = true;
+                        }
+                    }
+                    if (ended) {  // Scene.h:348: the sample's colour, parked until its unit's ordered fold
+                        const uint32_t n = min(g5.w & 0x3FFFFFFFu, (uint32_t)HRT_SP_UNIT - 1u);  // the path's number; stays inside the scratch
+                        fin_unit = g5.w >> 30;
+                        float *o = scratch + (size_t)fin_unit * ((size_t)HRT_SP_UNIT * 3u) + (size_t)n * 3u;
+                        o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
+                        freed = true;
+                    }
+                }
+                // spheres + squares + mesh gates for every lane of the chunk that has a new ray
+                bool to_mesh = false;
+                SEG(3);  // state written back / sample stored
+                Hit hn;
+                hn.kind = 0; hn.index = 0; hn.t = HRT_FLT_MAX; hn.tri = 0; hn.a0 = 0.f; hn.a1 = 0.f;
+                uint32_t pmn = 0;
+                if (trace) {
+                    hn = prims_hit(cx, ray);
+                    SEG(4);  // spheres + squares
+                    pmn = has_mesh ? mesh_gates(cx, ray) : 0u;
+                    SEG(5);  // mesh gates
+                }
+                if (trace) {
+                    sp_store_ray_hit(L, slot, ray, hn, pmn);
+                    if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
+                    to_mesh = pmn != 0u;
+                    kind = hn.kind;
+                }
+                sp_push_all(L, C, parity ^ 1u, trace ? (to_mesh ? 0u : 1u + kind) : (freed ? 5u : SP_TO_NONE), slot);
+#pragma unroll
+                for (uint32_t k = 0; k < HRT_SP_UNITS; ++k) fin[k] += (uint32_t)__popcll(__ballot(freed && fin_unit == k));
+                SEG(6);  // record stores + queue appends
+#ifdef HRT_SP_SEG
+                if (seg_on) seg[7] += 1;
+#endif
             }
+#ifdef HRT_SP_DEBUG
+            dbg_class[dbg_k] += __builtin_readcyclecounter() - dbg_c0;
+#endif
         }
-        __syncthreads();
-        for (uint32_t i = tid; i < G * 192u; i += HRT_SP_WG) {
-            const uint32_t q = i / 3u, p = q & 63u, txy = tile_xy[q >> 6];
-            if (txy == 0xFFFFFFFFu) continue;  // no such tile: nothing to write
-            const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
-            float c = 0.f;
-            if (px < R.w && py < R.h) c = R.accumulate ? L.run[i] : L.run[i] / (float)R.spp;  // main.cpp:195; progressive mode keeps the sum
-            R.out_tiles[(size_t)j * 192u + i] = c;
+#ifdef HRT_SP_DEBUG
+        dbg_work += __builtin_readcyclecounter() - dbg_w0;
+        if (ngen == 0u) { dbg_tail += __builtin_readcyclecounter() - dbg_w0; ++dbg_tail_cycles; }  // cycles of the drain: nothing left to start
+#endif
+        // this wave's part of the cycle is done: its records are in memory and its queue entries in LDS before it arrives
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {  // ... and its finished samples in the scratch before their units see them finished
+#pragma unroll
+            for (uint32_t k = 0; k < HRT_SP_UNITS; ++k)
+                if (fin[k]) atomicSub(&U[k].outstanding, fin[k]);
         }
+#pragma unroll
+        for (uint32_t k = 0; k < HRT_SP_UNITS; ++k) fin[k] = 0u;
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&C.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = SP_UNI(arrived);
+#ifdef HRT_SP_DEBUG
+        const unsigned long long dbg_s0 = __builtin_readcyclecounter();
+#endif
+        if (arrived + 1u == (HRT_SP_WG / 64u) * kcyc[st]) serial_section(C, L.q);  // the last wave prepares the stream's next cycle
+#ifdef HRT_SP_DEBUG
+        dbg_serial += __builtin_readcyclecounter() - dbg_s0;
+#endif
+        ++kcyc[st];
     }
+    L.q = q_all;
+    __syncthreads();
+    if (SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;  // uniform: read behind the barrier
+
 #ifdef HRT_SP_SEG
     if (lane == 0 && R.stamps)
         for (int k = 0; k < 8; ++k) atomicAdd(R.stamps + k, seg[k]);
