@@ -30,9 +30,10 @@
 //
 // DETERMINISM.  A path is keyed (pixel, sample) as before, so the schedule cannot change its random numbers or
 // its arithmetic.  A work unit is up to 16 tiles x 64 pixels x the samples of one fold (<= HRT_SP_UNIT paths);
-// finished samples go to a per-workgroup scratch indexed by sample-major path number and are folded into the
-// pixel sums in sample order when the unit has drained: the fold is the reference's `image += color` order
-// (main.cpp:193), bit for bit, whatever order paths finished in.
+// HRT_SP_UNITS units are in flight, so that new paths come from the next unit while the long paths of the last one
+// are still bouncing.  Finished samples go to the unit's part of a per-workgroup scratch, indexed by sample-major
+// path number, and are added to the pixel sums in sample order once the unit's last path has finished: the fold is
+// the reference's `image += color` order (main.cpp:193), bit for bit, whatever order paths finished in.
 #include "hrt_device.h"
 
 #ifndef HRT_SP_POOL
