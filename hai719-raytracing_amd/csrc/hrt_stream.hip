@@ -321,9 +321,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     // A1 B1 A2 B2 ...; a stage only ever waits for all waves to have passed the previous stage of the same stream, so there is no
     // cyclic wait.  Every wait is bounded (abort -> HRT_ERR_DEVICE on the host).
     //
-    // WORK UNITS.  A unit is G tiles x 64 pixels x the samples of one fold (<= HRT_SP_UNIT paths, its own half of the sample
+    // WORK UNITS.  A unit is G tiles x 64 pixels x the samples of one fold (<= HRT_SP_UNIT paths, its own part of the sample
     // scratch).  HRT_SP_UNITS are in flight: while the paths of one DRAIN (every path started, the long ones still bouncing), new paths
-    // come from the other, so the pool stays full.  (With one unit at a time a quarter of the cycles ran a draining, half-empty
+    // come from the next, so the pool stays full.  (With one unit at a time a quarter of the cycles ran a draining, half-empty
     // pool.)  When a unit's last path has finished, the next cycle of whichever stream notices carries its REDUCTION as ordinary
     // chunks: 64 (pixel, channel) columns each, the fold's samples added in sample order onto the running sums (main.cpp:193),
     // which live in out_tiles between folds; the last fold leaves the mean (main.cpp:195).  A path knows its unit slot (the two top
