@@ -1,4 +1,4 @@
-# scratch batch for one gpurun call (edited per experiment)
-bash tools/profile.sh r02 > gpurun_out/profile_r02.log 2>&1; tail -14 gpurun_out/profile_r02.log
-cp gpurun_out/prof_r02/r02_pmc.json profiles/r02_pmc.json
-python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r02g.log 2>&1; tail -c 300 gpurun_out/bench_r02g.log
+# scratch batch for one gpurun call (edited per experiment): the full GPU suite, smoke, default bench
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/bench_default.log 2>&1; tail -c 200 gpurun_out/bench_default.log
