@@ -1,4 +1,2 @@
-# scratch batch for one gpurun call (edited per experiment): the full GPU suite, smoke, default bench
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > gpurun_out/bench_default.log 2>&1; tail -c 200 gpurun_out/bench_default.log
+# scratch batch for one gpurun call (edited per experiment)
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests.log 2>&1; tail -5 gpurun_out/gpu_tests.log
