@@ -951,6 +951,12 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
             uint32_t glog = 0;
             while ((2u << glog) <= HRT_SP_MAXG && (per_tile << (glog + 1u)) <= HRT_SP_UNIT) ++glog;
             R.sp_group_log2 = glog;
+            // Few, heavy tiles (a rank's share of a frame at thousands of samples per pixel): the launch ends when the last
+            // workgroup finishes its last item, and an item is a whole tile's samples -- in order, so a tile cannot be split
+            // across workgroups by samples.  Split it by ROWS instead: bands of 4, 2 rows until a workgroup has ~64 items.
+            uint32_t band = 0;
+            while (glog == 0u && band < 2u && ((uint64_t)R.tiles_owned << band) < 64ull * grid && (64u >> (band + 1u)) * (uint64_t)std::min<uint32_t>(spp, HRT_SP_SCHUNK) >= 4096u) ++band;
+            R.sp_band_log2 = band;
         }
         const size_t need_floats = (size_t)grid * HRT_SP_UNITS * HRT_SP_UNIT * 3u;  // HRT_SP_UNITS units in flight per workgroup
         if (s->sp_scratch_cap < need_floats) {

@@ -120,5 +120,7 @@ struct DRender {
     unsigned long long *stamps;  // 16 cycle counters, written only by -DHRT_STAMPS diagnostic builds
     float *sp_scratch;           // streaming kernel: per-workgroup [sample][pixel][rgb] scratch of one sample chunk
     uint32_t sp_group_log2;      // streaming kernel: log2 of the tiles per work unit
+    uint32_t sp_band_log2;       // streaming kernel: a work unit is one ROW BAND of a tile, 8 x (8 >> this) pixels (then one tile per unit): finer
+                                 // items on the tile queue when tiles are few and heavy (many samples per pixel)
     uint32_t *sp_pool;           // streaming kernel built with HRT_SP_GLOBAL: per-workgroup path records
 };

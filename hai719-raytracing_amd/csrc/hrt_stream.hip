@@ -291,7 +291,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     const bool has_mesh = cx.S->n_meshes != 0u;
     const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
     float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNITS * HRT_SP_UNIT * 3u);  // one part per unit slot
-    const uint32_t glog = R.sp_group_log2, G = 1u << glog, upix = 64u << glog;  // tiles and pixels per unit
+    const uint32_t glog = R.sp_group_log2, G = 1u << glog, blog = R.sp_band_log2;  // tiles per unit; or ONE row band of a tile, 8 x (8 >> blog) pixels
+    const uint32_t upix = (64u << glog) >> blog, upix_log2 = 6u + glog - blog;     // pixels per unit
+    const uint32_t items = R.tiles_owned << blog;                                  // what the tile queue hands out: tiles, or bands of tiles
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 #ifndef HRT_SP_SEG_KIND
@@ -380,16 +382,16 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     if (cur == HRT_SP_UNITS && SH.tiles_done == 0u)
                         for (uint32_t k = 0; k < HRT_SP_UNITS; ++k)
                             if (cur == HRT_SP_UNITS && U[k].state == SP_U_FREE) {
-                                const uint32_t j = atomicAdd(R.tile_counter, G);
-                                if (j >= R.tiles_owned) { SH.tiles_done = 1u; break; }  // finite queue
+                                const uint32_t j = atomicAdd(R.tile_counter, G);  // item: tile slot (G of them), or tile slot << blog | band
+                                if (j >= items) { SH.tiles_done = 1u; break; }  // finite queue
                                 SpUnit &u = U[k];
                                 u.j = j; u.s0 = 0; u.ns = min(per_fold, R.spp); u.gen_next = 0; u.gen_total = upix * u.ns;
                                 __hip_atomic_store(&u.outstanding, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 for (uint32_t t = 0; t < G; ++t) {
                                     uint32_t xy = 0xFFFFFFFFu;
-                                    if (j + t < R.tiles_owned) {
-                                        const uint32_t tile = R.rank + (j + t) * R.world;
-                                        xy = ((tile % R.tiles_x) * 8u) | (((tile / R.tiles_x) * 8u) << 16);
+                                    if (j + t < items) {
+                                        const uint32_t tile = R.rank + ((j + t) >> blog) * R.world, band = (j + t) & ((1u << blog) - 1u);
+                                        xy = ((tile % R.tiles_x) * 8u) | (((tile / R.tiles_x) * 8u + band * (8u >> blog)) << 16);  // the band's first row
                                     }
                                     tile_xy[k * HRT_SP_MAXG + t] = xy;
                                 }
@@ -510,7 +512,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         if (SP_UNI(C.done)) { fin_mask |= 1u << st; continue; }
         const uint32_t parity = SP_UNI(C.parity);
         const uint32_t ngen = SP_UNI(C.ngen), n0 = SP_UNI(C.gen_n0), gs = SP_UNI(C.gen_slot), s0 = SP_UNI(C.gen_s0);
-        const uint32_t red = SP_UNI(C.red_slot), nR = red < HRT_SP_UNITS ? (G * 192u + 63u) >> 6 : 0u;  // reduction chunks: 64 columns each
+        const uint32_t red = SP_UNI(C.red_slot), nR = red < HRT_SP_UNITS ? (upix * 3u + 63u) >> 6 : 0u;  // reduction chunks: 64 columns each
         const uint32_t cTin = SP_UNI(C.cQ[0][parity]);
         const uint32_t cK0 = SP_UNI(C.cQ[1][parity]), cK1 = SP_UNI(C.cQ[2][parity]), cK2 = SP_UNI(C.cQ[3][parity]),
                        cK3 = SP_UNI(C.cQ[4][parity]);
@@ -538,8 +540,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 // path pool's plain loads and stores rely on.
                 const uint32_t i = c * 64u + lane;  // pixel-of-unit * 3 + channel
                 const uint32_t rj = SP_UNI(C.red_j), rs0 = SP_UNI(C.red_s0), rns = SP_UNI(C.red_ns);
-                if (i < G * 192u && rj + i / 192u < R.tiles_owned) {
-                    float *out = R.out_tiles + (size_t)rj * 192u + i;
+                if (i < upix * 3u && rj + i / (192u >> blog) < items) {  // (rj counts tiles -- G of them, 192 columns each -- or bands: one per unit)
+                    float *out = R.out_tiles + (size_t)rj * (192u >> blog) + i;
                     // the running sum: samples [0, rs0) of this launch, on top of the earlier launches' in progressive mode
                     float acc = (rs0 != 0u || R.accumulate) ? *out : 0.f;
                     const float *col = scratch + (size_t)red * ((size_t)HRT_SP_UNIT * 3u) + i;
@@ -641,7 +643,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 if (act && is_gen) {
                     slot = qFi[e] & (HRT_SP_POOL - 1u);
                     const uint32_t n = n0 + e;  // path n of the unit = (sample n / upix, pixel n % upix)
-                    const uint32_t q = n & (upix - 1u), s = s0 + (n >> (6u + glog));
+                    const uint32_t q = n & (upix - 1u), s = s0 + (n >> upix_log2);
                     const uint32_t p = q & 63u, txy = tile_xy[gs * HRT_SP_MAXG + (q >> 6)];
                     const uint32_t px = (txy & 0xFFFFu) + (p & 7u), py = (txy >> 16) + (p >> 3);
                     if (txy != 0xFFFFFFFFu && px < R.w && py < R.h) {
