@@ -20,7 +20,7 @@
 // lanes (__shfl of the base).
 //
 // The pool is split into HRT_SP_STREAMS = 2 streams, each with its own slots, queues and cycle counter, and there is
-// no barrier inside a fold: a wave that finds no chunk left in a stream's cycle ARRIVES (an LDS counter) and goes on
+// no barrier in the scheduler: a wave that finds no chunk left in a stream's cycle ARRIVES (an LDS counter) and goes on
 // with the other stream; the wave whose arrival completes the cycle runs the serial section (new path numbers, buffer
 // swap, unused free slots) and publishes the next cycle (see the comment at the scheduler, below).  Every control
 // value a loop condition depends on is read back through readfirstlane, so those loops are provably wave-uniform

@@ -16,6 +16,6 @@ for spec in sys.argv[1:] or ["cornell_mesh:32"]:
     cls = list(o[5:11]); tot = max(1, sum(cls))
     names = ["T (KD walk)", "mesh hits", "sphere hits", "square hits", "misses", "G (new paths)"]
     print(f"{name} {w}x{h}@{spp}: kernel {st.kernel_ms:.1f} ms; waves in chunk loops {100 * work / max(1, alive):.1f} % of their life, "
-          f"serial section {100 * serial / max(1, alive):.1f} %, waiting for a cycle {100 * o[11] / max(1, alive):.1f} %, at the end-of-fold barrier {100 * o[12] / max(1, alive):.1f} %, {cycles / 4096:.0f} cycles per workgroup-wave, {chunks / max(1, cycles):.2f} chunks per wave per cycle")
-    print(f"   drain of the folds (cycles with no path left to start): {100 * o[14] / max(1, cycles):.1f} % of the cycles, {100 * o[13] / max(1, work):.1f} % of the clocks in chunk loops")
+          f"serial section {100 * serial / max(1, alive):.1f} %, waiting for a cycle {100 * o[11] / max(1, alive):.1f} %, {cycles / 4096:.0f} cycles per workgroup-wave, {chunks / max(1, cycles):.2f} chunks per wave per cycle")
+    print(f"   cycles that started no path (every unit in flight draining, or the end of the launch): {100 * o[14] / max(1, cycles):.1f} % of the cycles, {100 * o[13] / max(1, work):.1f} % of the clocks in chunk loops")
     print("   " + "  ".join(f"{n} {100 * c / tot:.1f}%" for n, c in zip(names, cls)))
