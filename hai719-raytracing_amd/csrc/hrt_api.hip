@@ -920,7 +920,12 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     // Which schedule of the same arithmetic (all give identical pixels).  Measured on MI355X at 1080p: the
     // workgroup-streaming kernel wins where bounces diverge -- meshes (+3..10 %) and lit open scenes (random_spheres
     // +30 %) -- and loses on a closed box of squares (-45 %), where the lane-per-pixel kernel keeps its lanes busy anyway.
-    const bool stream_pays = s->d.n_meshes > 0u || s->d.n_lights > 0u;
+    // The streaming kernel pays where bounces diverge (meshes, lights) -- and on SMALL frames with many samples per pixel: the
+    // lane-per-pixel kernel gives a wave 64 pixels and walks their samples one after the other, so below ~5 k tiles (20 waves
+    // on each of 256 CUs) its time is spp x one sample's latency, while the streaming kernel spreads samples over the whole pool
+    // (Cornell box 256 x 256 on MI355X: 4 spp 0.22 vs 0.29 ms, 64 spp 3.22 vs 1.52 ms; 1080p @ 16: 8.6 vs 11.1 ms).
+    const bool small_and_deep = R.tiles_owned <= 5120u && spp >= 8u;
+    const bool stream_pays = s->d.n_meshes > 0u || s->d.n_lights > 0u || small_and_deep;
     // the streaming kernel stages the per-object tables (squares, materials, spheres, mesh records) in LDS beside its queues
     const bool stream_fits = (size_t)s->d.tab_rows * 16u <= 48u * 1024u;
     if ((flags & HRT_FLAG_STREAM_KERNEL) && !stream_fits)
