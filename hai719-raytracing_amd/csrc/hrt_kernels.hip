@@ -510,8 +510,8 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
         if (!(ref & HRT_KD_LEAF)) ref = kd_descend(g_units, cx, ref, p, ray.d);  // two levels
         if (ref & HRT_KD_LEAF) {
             const uint32_t lu = ref & ~HRT_KD_LEAF;
-            uint4 l0, l1;
-            kd_fetch2(g_units, cx, lu, l0, l1);
+            uint4 l0, l1, rp0, rp1;
+            kd_fetch4(g_units, cx, lu, l0, l1, rp0, rp1);  // the ropes with the header: one round trip less per cell
             if (cnt == ~0u) { first = tri_base + l0.w; cnt = l1.w; k = 0; }
 #ifdef HRT_ABL_NO_TRI  // ablation only
             k = cnt;
@@ -531,7 +531,7 @@ __device__ __forceinline__ bool mesh_traverse(const CX &cx, cmesh M, const Ray &
                 } else {
                     t_entry = fmaxf(t_entry, t_exit);
                     p = ray.o + t_entry * ray.d;
-                    const uint4 rp = kd_fetch(g_units, cx, lu + 2 + (face >> 2));
+                    const uint4 rp = (face >> 2) ? rp1 : rp0;
                     const uint32_t sel = face & 3u;
                     ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
                     cnt = ~0u;
