@@ -211,10 +211,11 @@ void fold_triangle(const H3 c[3], uint32_t id, std::vector<float4> &tris, std::v
     const float d00 = h_dot(e1, e1), d01 = h_dot(e1, e2), d11 = h_dot(e2, e2);
     const float denom = h_msub(d00, d11, d01, d01);
     planes.push_back(make_float4(n.x, n.y, n.z, h_dot(c[0], n)));
-    tris.push_back(make_float4(c[0].x, c[0].y, c[0].z, as_float(id)));
+    (void)denom;  // = fl(fl(d00 * d11) - fl(d01 * d01)): the kernels recompute it from the rows, in the same two roundings (tri_inside)
+    tris.push_back(make_float4(c[0].x, c[0].y, c[0].z, d11));
     tris.push_back(make_float4(e1.x, e1.y, e1.z, d00));
     tris.push_back(make_float4(e2.x, e2.y, e2.z, d01));
-    tris.push_back(make_float4(d11, denom, 0.f, 0.f));
+    tris.push_back(make_float4(as_float(id), 0.f, 0.f, 0.f));  // read only when the triangle is shaded
 }
 
 template <class T>

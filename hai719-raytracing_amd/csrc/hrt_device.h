@@ -20,7 +20,7 @@
 //                 its nb reference leaf boxes {lo, 0} {hi, 0} (its rows sit behind the mesh's leaf-ordered soup); bounding entry
 //                 {lo, HRT_EXC_INNER} {hi, skip}; threaded depth-first
 //   triangles     leaf-ordered soup in two arrays by slot: planes {n, D} (16 B: the planes of a leaf's triangles share a cache line) and
-//                 rows {c0, id} {e1, d00} {e2, d01} {d11, denom, -, -} (one 64-byte line, read only when the plane is hit in front)
+//                 rows {c0, d11} {e1, d00} {e2, d01} {id, -, -, -} (one 64-byte line; three rows read when the plane is hit in front, the id at shading)
 //                 (Triangle.h:32-37, 62-75 constants folded on the host in the reference's arithmetic)
 //   colours       float4 per face / per vertex (+ uint4 vertex ids per triangle)
 //   texels        RGBA8 packed in a u32, one table entry {offset, w, h} per image
@@ -34,7 +34,7 @@
 #define HRT_QUAD_ROWS 7
 #define HRT_SPHERE_ROWS 2
 #define HRT_MAT_ROWS 8
-#define HRT_TRI_ROWS 4   // {c0, id} {e1, d00} {e2, d01} {d11, denom}: one 64-byte line per triangle; the plane {n, D} lives in DScene::tri_planes
+#define HRT_TRI_ROWS 4   // {c0, d11} {e1, d00} {e2, d01} {id}: one 64-byte line per triangle; the plane {n, D} lives in DScene::tri_planes
 #define HRT_EXC_INNER 0xFFFFFFFFu  // first word of a bounding entry of a mesh's exception list (DScene::exceptions)
 #define HRT_QUAD_FLAG_GLASS 1u
 #define HRT_QUAD_FLAG_MOVING 2u

@@ -362,7 +362,8 @@ __device__ __forceinline__ uint32_t kd_descend(gu4 g, const CX &cx, uint32_t ref
 // computeBarycentricCoordinates' constants folded on the host, then the leaf's strict `<` against the best so far
 // (KDTree.cpp:44).  True when this triangle became the best.  The soup is two arrays indexed by slot:
 //   planes  {n, D}: 16 bytes, so the planes of a leaf's (<= 4) triangles share one cache line -- the plane test rejects most
-//   rows    {c0, id} {e1, d00} {e2, d01} {d11, denom}: one aligned 64-byte line, fetched only by a triangle whose plane is hit in front
+//   rows    {c0, d11} {e1, d00} {e2, d01} {id}: one aligned 64-byte line; the first three fetched only by a triangle whose plane is hit in
+//           front (the denominator d00 d11 - d01^2 is recomputed, in the constructor's roundings), the id only when the triangle is shaded
 #ifndef HRT_LEAF_BATCH
 #define HRT_LEAF_BATCH 2   // triangles of a leaf tested per trip of a walk, their planes requested together
 #endif
@@ -379,18 +380,20 @@ __device__ __forceinline__ bool tri_plane_t(const float4 pl, const Ray &ray, flo
     t = (pl.w - dot(ray.o, n)) / dotRN;                   // :95
     return !(t < 0.f || !(t < best_t));                   // :96, then KDTree.cpp:44
 }
-__device__ __forceinline__ bool tri_inside(const float4 r0, const float4 r1, const float4 r2, const float4 r4, const Ray &ray, float t, float &u1, float &u2) {
+__device__ __forceinline__ bool tri_inside(const float4 r0, const float4 r1, const float4 r2, const Ray &ray, float t, float &u1, float &u2) {
     const f3 v2 = (ray.o + t * ray.d) - mk(r0);
     const float d20 = dot(v2, mk(r1)), d21 = dot(v2, mk(r2));
-    u1 = (r4.x * d20 - r2.w * d21) / r4.y;                // :72-74
-    u2 = (r1.w * d21 - r2.w * d20) / r4.y;
+    const float d00 = r1.w, d01 = r2.w, d11 = r0.w;
+    const float denom = d00 * d11 - d01 * d01;            // :66-70, the constructor's own two roundings: a row less to fetch per candidate
+    u1 = (d11 * d20 - d01 * d21) / denom;                 // :72-74
+    u2 = (d00 * d21 - d01 * d20) / denom;
     const float u0 = 1 - u1 - u2;
     return u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1;
 }
 __device__ __forceinline__ bool tri_test_plane(gf4 tr, const float4 pl, const Ray &ray, float &best_t, float &bu, float &bv) {
     float t, u1, u2;
     if (!tri_plane_t(pl, ray, best_t, t)) return false;
-    if (!tri_inside(ld(tr, 0), ld(tr, 1), ld(tr, 2), ld(tr, 3), ray, t, u1, u2)) return false;
+    if (!tri_inside(ld(tr, 0), ld(tr, 1), ld(tr, 2), ray, t, u1, u2)) return false;
     best_t = t; bu = u1; bv = u2;
     return true;
 }
@@ -963,10 +966,10 @@ __device__ __forceinline__ Surface shade(const CX &cx, const Ray &ray, const Hit
         const typename CX::tabmesh M = cx.tmesh + h.index;  // per-lane mesh record
         mat_id = M->material;
         const float4 m0 = ld(mats, HRT_MAT_ROWS * mat_id);
-        const float4 r0 = ld((gf4)S->tris, HRT_TRI_ROWS * h.tri), r3 = ld((gf4)S->tri_planes, h.tri);
+        const float4 r0 = ld((gf4)S->tris, HRT_TRI_ROWS * h.tri + 3u), r3 = ld((gf4)S->tri_planes, h.tri);  // r0.x: the triangle's id
         sf.n = mk(r3);  // Triangle.h:32-37 flat normal, folded on the host
         sf.albedo = mk(m0);
-        const uint32_t tid = __float_as_uint(r0.w);
+        const uint32_t tid = __float_as_uint(r0.x);
         const int ct = M->color_type;
         gf4 colors = (gf4)S->colors;
         if (ct == 1) {
@@ -1303,7 +1306,7 @@ extern "C" __global__ void hrt_aov_kernel(const DRender R, uint32_t which, float
     f3 o = mk(0.f, 0.f, 0.f);
     if (which == 0u) {
         float id = -1.f;
-        if (h.kind == 3u) id = (float)__float_as_uint(ld((gf4)cx.S->tris, HRT_TRI_ROWS * h.tri).w);
+        if (h.kind == 3u) id = (float)__float_as_uint(ld((gf4)cx.S->tris, HRT_TRI_ROWS * h.tri + 3u).x);
         else if (h.kind) id = (float)h.index;
         o = mk(h.kind ? h.t : 0.f, (float)h.kind, id);
     } else if (h.kind) {
