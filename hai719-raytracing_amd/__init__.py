@@ -168,6 +168,8 @@ def device_lib() -> C.CDLL:
                                          C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         lib.hrt_multi_destroy.argtypes = [C.c_void_p]
         lib.hrt_multi_destroy.restype = None
+        lib.hrt_multi_gather.argtypes = [C.c_void_p]
+        lib.hrt_multi_gather.restype = C.c_char_p
         lib.hrt_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                          C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_void_p, C.POINTER(Stats)]
         lib.hrt_debug_kat.argtypes = [C.c_uint32, C.POINTER(Camera), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -384,7 +386,13 @@ class MultiScene:
         rc = self._lib.hrt_multi_create(desc, len(devices), arr, C.byref(self._h))
         if rc < 0:
             raise HrtError(f"hrt error {rc}: {self._lib.hrt_last_error().decode()}")
+        self.note = self._lib.hrt_last_error().decode()  # what creation fell back from, if anything
         _inited = True
+
+    @property
+    def gather(self) -> str:
+        """"rccl" (one ncclGather over the handle's communicators) or "peer" (hipMemcpyPeerAsync per slot)."""
+        return self._lib.hrt_multi_gather(self._h).decode()
 
     def close(self):
         if self._h:

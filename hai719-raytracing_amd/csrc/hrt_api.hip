@@ -7,6 +7,9 @@
 #include "hrt_output.hip"
 #include "hrt_kat.hip"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is opened with dlopen by hrt_multi_create (hrt_multi.hip)
+
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -322,7 +325,7 @@ void hrt_shutdown(void) { g_rt.ready = false; g_rt.dev_cus.clear(); }
 
 void hrt_scene_destroy(hrt_scene *s) {
     if (!s) return;
-    if (g_rt.ready && s->device != g_rt.device) (void)use_device(s->device);
+    if (g_rt.ready) (void)use_device(s->device);
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->tile_counter) (void)hipFree(s->tile_counter);
     if (s->stamps) (void)hipFree(s->stamps);
@@ -770,6 +773,18 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     d.n_kd_units = (uint32_t)units.size();
     s->lds_units = std::min<uint32_t>(d.n_kd_units, g_rt.lds_budget / 16u) & ~3u;  // whole 64-byte lines: no treelet or leaf straddles
     d.dark_sky = D.dark_sky;
+    {   // exact path pruning needs 0 x value == 0: no colour of the scene may be infinite or NaN (hrt_device.h DScene::prune_ok)
+        bool finite = true;
+        auto fin3 = [&](const float *v) { finite = finite && std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); };
+        for (uint32_t i = 0; i < D.n_materials; ++i) {
+            const hrt_material &m = D.materials[i];
+            fin3(m.albedo); fin3(m.checker1); fin3(m.checker2); fin3(m.light_color);
+            finite = finite && std::isfinite(m.light_intensity);
+        }
+        for (uint32_t i = 0; i < D.n_lights; ++i) fin3(D.lights[i].color);
+        for (const float4 &c : colors) finite = finite && std::isfinite(c.x) && std::isfinite(c.y) && std::isfinite(c.z);
+        d.prune_ok = finite ? 1u : 0u;
+    }
     d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
     HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&s->stamps, 16 * sizeof(unsigned long long)));
@@ -870,7 +885,8 @@ static int fill_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t
                        uint32_t flags, uint32_t rank, uint32_t world, DRender &R, hipStream_t stream) {
     if (!s || !cam) return fail(HRT_ERR_INVALID, "render: NULL argument");
     if (!g_rt.ready) return fail(HRT_ERR_STATE, "render: call hrt_init first");
-    if (s->device != g_rt.device) { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }  // a scene lives on its device
+    { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }  // a scene lives on its device.  Unconditional: HIP's current
+                                                                               // device is per thread, g_rt's copy of it per process
     if (!w || !h || !spp) return fail(HRT_ERR_INVALID, "render: w, h and spp must be positive");
     if ((uint64_t)w * h > 0x7fffffffull) return fail(HRT_ERR_INVALID, "render: image too large");
     if (w > 65535u || h > 65535u) return fail(HRT_ERR_INVALID, "render: w and h must be below 65536 (tile origins are packed in 16 + 16 bits)");
@@ -1124,7 +1140,7 @@ int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, uns
 int hrt_check_last_launch(hrt_scene *s) {
     if (!s) return fail(HRT_ERR_INVALID, "hrt_check_last_launch: NULL scene");
     if (!s->timed) return HRT_OK;
-    if (s->device != g_rt.device) { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }
+    { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }
     HIP_TRY(hipEventSynchronize(s->ev1));
     unsigned long long gave_up = 0;
     HIP_TRY(hipMemcpy(&gave_up, s->stamps + 15, sizeof(gave_up), hipMemcpyDeviceToHost));
@@ -1159,6 +1175,7 @@ int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded, 
 
 int hrt_debug_read_stamps(hrt_scene *s, uint64_t out[16]) {
     if (!s || !out) return fail(HRT_ERR_INVALID, "hrt_debug_read_stamps: NULL argument");
+    { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, s->stamps, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return HRT_OK;
@@ -1177,6 +1194,8 @@ int hrt_render(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_t h, uint
                float *out_rgb, hrt_stats *stats) {
     if (!out_rgb) return fail(HRT_ERR_INVALID, "hrt_render: NULL output");
     if (!s) return fail(HRT_ERR_INVALID, "hrt_render: NULL scene");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "render: call hrt_init first");
+    { const int drc = use_device(s->device); if (drc != HRT_OK) return drc; }  // the frame and tile buffers below belong on the scene's device
     const auto t0 = std::chrono::steady_clock::now();
     const size_t tiles = hrt_tiles_total(w, h);
     const size_t tile_floats = tiles * 64 * 3, frame_floats = (size_t)w * h * 3;

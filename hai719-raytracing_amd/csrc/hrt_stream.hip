@@ -79,6 +79,13 @@
 #ifndef HRT_SP_DEFER
 #define HRT_SP_DEFER 1     // 1: only whole chunks run while the fold still has paths to start (see the serial section)
 #endif
+#ifndef HRT_SP_PRUNE
+#define HRT_SP_PRUNE 3     // exact path pruning (never in the proof builds; only when DScene::prune_ok): bit 0 -- a path whose throughput
+#endif                     // has become exactly (0, 0, 0) ends (every later term is throughput x a finite value = 0); bit 1 -- on the LAST
+                           // segment of a path in a scene without point lights only the emission of the closest hit can still reach the
+                           // sample: when spheres + squares already give a closest hit that does not emit (a mesh in front of it emits
+                           // nothing either, Scene.h:288-299), or nothing and the sky is dark, the path ends there -- no mesh walk, no sixth
+                           // hit visit.  Same pixels bit for bit: rad + throughput x 0 == rad
 #define HRT_SP_QCAP (HRT_SP_POOL / HRT_SP_STREAMS)  // slots, and entries per queue, of one stream
 #define HRT_SP_NQ 8        // queues: T0 T1 A0 A1 B0 B1 F0 F1 (A: sphere hits from the front, quad hits from the back;
                            // B: misses from the front, mesh hits from the back -- a path sits in exactly one place)
@@ -290,6 +297,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         q_all[(i / HRT_SP_QCAP) * (HRT_SP_NQ * HRT_SP_QCAP) + (2 * 3 + 0) * HRT_SP_QCAP + (i % HRT_SP_QCAP)] = (uint16_t)i;
     const bool has_mesh = cx.S->n_meshes != 0u;
     const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
+    const bool prune = !EXACT && HRT_SP_PRUNE != 0 && cx.S->prune_ok != 0u;                // see HRT_SP_PRUNE
+    const bool sky_is_zero = cx.S->skybox_image < 0 && cx.S->dark_sky != 0;                // Scene.h:149-152: a miss adds nothing
     float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNITS * HRT_SP_UNIT * 3u);  // one part per unit slot
     const uint32_t glog = R.sp_group_log2, G = 1u << glog, blog = R.sp_band_log2;  // tiles per unit; or ONE row band of a tile, 8 x (8 >> blog) pixels
     const uint32_t upix = (64u << glog) >> blog, upix_log2 = 6u + glog - blog;     // pixels per unit
@@ -635,8 +644,10 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 const uint16_t *qHi = (c < e3 || c >= e2) ? qBi : qAi;
                 const uint32_t e = (c - first) * 64u + lane;
                 const bool act = e < fill;
-                uint32_t slot = 0, kind = 0, fin_unit = 0;
+                uint32_t slot = 0, kind = 0, fin_unit = 0, pnum = 0;
                 bool trace = false, freed = false;  // trace: the path has a new ray to intersect; freed: its path has ended (unit fin_unit)
+                bool ended = false, last_seg = false;  // ended: the sample's colour `rad` is final; last_seg: the new ray is the path's last segment
+                f3 rad = mk(0.f, 0.f, 0.f);
                 SEG_START(HRT_SP_SEG_KIND == 1 && !is_gen && c >= e1 && c < e2);  // square-hit chunks
                 Ray ray;
                 ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
@@ -675,13 +686,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
                     ray.time = __uint_as_float(g5.x);
                     f3 thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
-                    f3 rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
+                    rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
                     int remaining = (int)g7.w;
+                    pnum = g5.w;
 #ifdef HRT_SP_SEG
                     asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
 #endif
                     SEG(0);  // record loaded
-                    bool ended;
                     if (h.kind == 0u) {
                         rad = rad + thr * sky(cx, ray.d, remaining);
                         ended = true;
@@ -698,18 +709,13 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         SEG(2);  // scatter
                         --remaining;
                         ended = (remaining == 0);
+                        if ((HRT_SP_PRUNE & 1) && prune && thr.x == 0.f && thr.y == 0.f && thr.z == 0.f) ended = true;  // nothing can reach the sample any more
                         if (!ended) {
                             sp_st4(L, 6, slot, sp_pack(thr.x, thr.y, thr.z, rad.x));
                             sp_st4(L, 7, slot, make_uint4(__float_as_uint(rad.y), __float_as_uint(rad.z), rng.i, (uint32_t)remaining));
                             trace = true;
+                            last_seg = (HRT_SP_PRUNE & 2) && !LIGHTS && prune && remaining == 1;
                         }
-                    }
-                    if (ended) {  // Scene.h:348: the sample's colour, parked until its unit's ordered fold
-                        const uint32_t n = min(g5.w & 0x3FFFFFFFu, (uint32_t)HRT_SP_UNIT - 1u);  // the path's number; stays inside the scratch
-                        fin_unit = g5.w >> 30;
-                        float *o = scratch + (size_t)fin_unit * ((size_t)HRT_SP_UNIT * 3u) + (size_t)n * 3u;
-                        o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
-                        freed = true;
                     }
                 }
                 // spheres + squares + mesh gates for every lane of the chunk that has a new ray
@@ -723,6 +729,24 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     SEG(4);  // spheres + squares
                     pmn = has_mesh ? mesh_gates(cx, ray) : 0u;
                     SEG(5);  // mesh gates
+                }
+                if (last_seg) {  // HRT_SP_PRUNE bit 1: the closest hit of this ray is only asked whether it emits
+                    bool dead;
+                    if (hn.kind == 0u) {
+                        dead = sky_is_zero;  // no sphere, no square: a mesh emits nothing and neither does this sky
+                    } else {
+                        const uint32_t mat = hn.kind == 1u ? __float_as_uint(ld(cx.ts, HRT_SPHERE_ROWS * hn.index + 1u).w)
+                                                           : __float_as_uint(ld(cx.tq, HRT_QUAD_ROWS * hn.index + 4u).w);
+                        dead = __float_as_uint(ld(cx.tm, HRT_MAT_ROWS * mat + 1u).w) == 0u;  // Material::emit, Material.cpp:13-15
+                    }
+                    if (dead) { trace = false; ended = true; }
+                }
+                if (ended) {  // Scene.h:348: the sample's colour, parked until its unit's ordered fold
+                    const uint32_t n = min(pnum & 0x3FFFFFFFu, (uint32_t)HRT_SP_UNIT - 1u);  // the path's number; stays inside the scratch
+                    fin_unit = pnum >> 30;
+                    float *o = scratch + (size_t)fin_unit * ((size_t)HRT_SP_UNIT * 3u) + (size_t)n * 3u;
+                    o[0] = rad.x / 6.f; o[1] = rad.y / 6.f; o[2] = rad.z / 6.f;
+                    freed = true;
                 }
                 if (trace) {
                     sp_store_ray_hit(L, slot, ray, hn, pmn);

@@ -83,6 +83,11 @@ int main(int argc, char **argv) {
         std::cerr << hrt_last_error() << std::endl;
         return EXIT_FAILURE;
     }
+    if (multi) {  // which gather the tiles take to slot 0, and anything creation fell back from
+        const std::string note = hrt_last_error();
+        std::cout << "Image tiles across " << devices.size() << " GPU slot(s), gather: " << hrt_multi_gather(multi)
+                  << (note.empty() ? "" : " (" + note + ")") << std::endl;
+    }
     int rc = ray_trace_from_camera();  // the 'r' key
     hrt_scene_destroy(device_scene);
     hrt_multi_destroy(multi);

@@ -25,6 +25,9 @@
 extern "C" {
 #endif
 
+/* libhrt.so is built with -fvisibility=hidden: the functions declared here are everything it exports. */
+#define HRT_API __attribute__((visibility("default")))
+
 /* ---- compile-time constants of the path (reference src/Constants.h) ---- */
 #define HRT_MAXBOUNCES 6             /* Constants.h:11  MAXBOUNCES            */
 #define HRT_NB_ECH 10                /* Constants.h:12  shadow rays per light  */
@@ -202,54 +205,64 @@ typedef struct hrt_stats {
 typedef struct hrt_scene hrt_scene;   /* opaque: device-resident SoA scene */
 
 /* Prepares `device_ordinal` (once) and makes it the current device of the library: scenes are created on the current
- * device and stay there.  May be called for several devices; entry points that take a scene switch to its device. */
-int hrt_init(int device_ordinal);
-void hrt_shutdown(void);
-const char *hrt_last_error(void);
-int hrt_device_count(void);
+ * device and stay there.  May be called for several devices.  Entry points that take an hrt_scene or an hrt_multi switch
+ * the calling thread to that scene's device (every time: HIP's current device is per thread) and leave it current.
+ * Entry points that only take device POINTERS -- hrt_assemble_frame, hrt_finalize_tiles, hrt_encode_ppm -- and the
+ * scene-less debug calls (hrt_debug_kat, hrt_debug_path_stream) do not switch: they run on the calling thread's current
+ * device, which must be the one the pointers live on. */
+HRT_API int hrt_init(int device_ordinal);
+HRT_API void hrt_shutdown(void);
+HRT_API const char *hrt_last_error(void);
+HRT_API int hrt_device_count(void);
 
 /* Upload: repack the description into device SoA arrays.  The description
  * (and everything it points to) may be freed after the call returns. */
-int hrt_scene_create(const hrt_scene_desc *desc, hrt_scene **out);
-void hrt_scene_destroy(hrt_scene *scene);
+HRT_API int hrt_scene_create(const hrt_scene_desc *desc, hrt_scene **out);
+HRT_API void hrt_scene_destroy(hrt_scene *scene);
 
 /* Whole frame on the current device into a HOST buffer out_rgb[h*w*3]
  * (row-major x + y*w, as main.cpp:193).  Value = mean over spp of
  * Scene::rayTrace, gamma-corrected when HRT_FLAG_GAMMA. */
-int hrt_render(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
+HRT_API int hrt_render(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
                uint32_t spp, uint64_t seed, uint32_t flags, float *out_rgb,
                hrt_stats *stats /* may be NULL */);
 
 /* Several GPUs from ONE process -- the multi-GPU form of the reference's single caller ray_trace_from_camera()
  * (main.cpp:200-263).  Slot i of `device_ordinals` holds a replica of the scene on that device, renders the image tiles
- * i, i + n, i + 2n, ... on a stream of its own (all slots run at once), and its dense tile buffer is copied device to
- * device (xGMI between GPUs) into its block of a gather buffer on slot 0's device: ONE gather step, no reduction (slots
- * own disjoint pixels).  Slot 0 then de-interleaves the tiles and copies the frame to out_rgb (host, h*w*3).  The pixels
+ * i, i + n, i + 2n, ... on a stream of its own (all slots run at once), and its dense tile buffer travels device to
+ * device (xGMI between GPUs) into its block of a gather buffer on slot 0's device: ONE gather step -- an RCCL gather, or
+ * peer copies, see hrt_multi_gather -- and no reduction (slots own disjoint pixels).  Slot 0 then de-interleaves the tiles and copies the frame to out_rgb (host, h*w*3).  The pixels
  * are bit-identical to hrt_render's for any number of slots.  An ordinal may be repeated (several slots share a GPU),
  * which makes the path testable on a one-GPU machine.  hrt_multi_create prepares every listed device (hrt_init is not
  * needed first) and leaves slot 0's device current; stats: kernel_ms = the slowest slot's kernel.
  * hrt_render_multi = create + render + destroy in one call. */
 typedef struct hrt_multi hrt_multi;
-int hrt_multi_create(const hrt_scene_desc *desc, uint32_t n_devices, const int *device_ordinals, hrt_multi **out);
-int hrt_multi_render(hrt_multi *m, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
+HRT_API int hrt_multi_create(const hrt_scene_desc *desc, uint32_t n_devices, const int *device_ordinals, hrt_multi **out);
+HRT_API int hrt_multi_render(hrt_multi *m, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp, uint64_t seed,
                      uint32_t flags, float *out_rgb, hrt_stats *stats /* may be NULL */);
-void hrt_multi_destroy(hrt_multi *m);
-int hrt_render_multi(const hrt_scene_desc *desc, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp,
+HRT_API void hrt_multi_destroy(hrt_multi *m);
+/* Which gather this handle runs: "rccl" -- one ncclGather (rccl.h:745) to slot 0 over the communicators hrt_multi_create
+ * made with ncclCommInitAll, the default whenever the ordinals are distinct (one slot included) -- or "peer" --
+ * hipMemcpyPeerAsync per slot, used when an ordinal repeats or when HRT_MULTI_GATHER=peer is set in the environment
+ * (HRT_MULTI_GATHER=rccl makes a missing librccl.so or a failed communicator an error instead of a fallback).  After a
+ * successful hrt_multi_create, hrt_last_error() holds a note about anything that was fallen back from (else ""). */
+HRT_API const char *hrt_multi_gather(const hrt_multi *m);
+HRT_API int hrt_render_multi(const hrt_scene_desc *desc, const hrt_camera *cam, uint32_t w, uint32_t h, uint32_t spp,
                      uint64_t seed, uint32_t flags, uint32_t n_devices, const int *device_ordinals, float *out_rgb,
                      hrt_stats *stats /* may be NULL */);
 
 /* Multi-GPU building blocks (device pointers; `stream` is a hipStream_t cast
  * to void*, NULL = the default stream).  Asynchronous w.r.t. the host. */
-uint32_t hrt_tiles_total(uint32_t w, uint32_t h);
-uint32_t hrt_tiles_owned(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);
-int hrt_render_tiles(hrt_scene *scene, const hrt_camera *cam, uint32_t w,
+HRT_API uint32_t hrt_tiles_total(uint32_t w, uint32_t h);
+HRT_API uint32_t hrt_tiles_owned(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);
+HRT_API int hrt_render_tiles(hrt_scene *scene, const hrt_camera *cam, uint32_t w,
                      uint32_t h, uint32_t spp, uint64_t seed, uint32_t flags,
                      uint32_t rank, uint32_t world,
                      float *d_tiles /* device, hrt_tiles_owned()*HRT_TILE^2*3 */,
                      void *stream);
 /* Rank 0 after the gather: d_gathered holds world blocks of
  * tiles_per_rank_padded tiles (rank-major); writes the row-major frame. */
-int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded,
+HRT_API int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded,
                        uint32_t w, uint32_t h, uint32_t world,
                        float *d_frame /* device, h*w*3 */, void *stream);
 /* One hrt_scene carries one launch at a time (it owns the work-queue head, the path pool and the camera block of the
@@ -260,20 +273,20 @@ int hrt_assemble_frame(const float *d_gathered, uint32_t tiles_per_rank_padded,
  * up (its scheduler has a cycle bound so that a bug can never spin the GPU): the tiles of that launch are then
  * incomplete and must not be used.  hrt_render and hrt_last_kernel_ms call it themselves; callers of the asynchronous
  * entry points (hrt_render_tiles, hrt_render_accumulate) call it before they consume or ship the tiles. */
-int hrt_check_last_launch(hrt_scene *scene);
+HRT_API int hrt_check_last_launch(hrt_scene *scene);
 /* Timing of the last hrt_render_tiles on this scene (after a sync). */
-int hrt_last_kernel_ms(hrt_scene *scene, double *ms);
-int hrt_kernel_info(hrt_stats *out);
+HRT_API int hrt_last_kernel_ms(hrt_scene *scene, double *ms);
+HRT_API int hrt_kernel_info(hrt_stats *out);
 
 /* Parity instruments (deterministic, no RNG): first-hit AOVs through pixel
  * centres at time 0.  which: 0 = (t, kind, index) with kind 1 sphere / 2 square /
  * 3 mesh and index = object or triangle id (t = 0, index = -1 on a miss),
  * 1 = shading normal, 2 = albedo, 3 = emission.  out_rgb: host, h*w*3. */
-int hrt_render_aov(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
+HRT_API int hrt_render_aov(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
                    uint32_t which, float *out_rgb);
 /* Draws 0..n-1 of the per-path RNG stream (seed, pixel, sample) as the kernel
  * produces them (DESIGN.md "RNG stream").  out: host, n floats. */
-int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out);
+HRT_API int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out);
 
 /* Known-answer instrument: runs the DEVICE functions of the trace path on caller vectors (one lane each), so that a test
  * can compare the device arithmetic bit for bit with vectors produced by the reference's own code instead of inferring
@@ -291,14 +304,14 @@ int hrt_debug_path_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32
  *   HRT_KAT_NORMALIZE -                                         v        3: v / |v| (Vec3.h:46) */
 enum { HRT_KAT_CAMERA = 0, HRT_KAT_TRIANGLE = 1, HRT_KAT_AABB = 2, HRT_KAT_SPHERE = 3, HRT_KAT_QUAD = 4, HRT_KAT_OPTICS = 5,
        HRT_KAT_NORMALIZE = 6 };
-int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, const float *in, uint32_t n, float *out);
+HRT_API int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *prim, const float *in, uint32_t n, float *out);
 
 /* Cycle counters per kernel stage of the last launch; all zero unless libhrt.so was built with
  * -DHRT_STAMPS (diagnostic build, tools/variants.sh).  out: 16 values. */
-int hrt_debug_read_stamps(hrt_scene *scene, uint64_t out[16]);
+HRT_API int hrt_debug_read_stamps(hrt_scene *scene, uint64_t out[16]);
 
 /* Output stage of main.cpp:252-262: P3 ASCII with (int)(255*min(1,c)). */
-int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
+HRT_API int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
 
 /* ---- progressive rendering / resume (replaces the all-or-nothing sample loop main.cpp:188-195)
  * d_sum_tiles (device, hrt_tiles_owned()*HRT_TILE^2*3 floats, zeroed by the caller before the first call) holds
@@ -307,19 +320,19 @@ int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
  * the sum continues in the same order, k calls covering [0, N) leave exactly the bits one hrt_render_tiles of N
  * samples would have summed: a render can be previewed, stopped, checkpointed (copy the buffer) and resumed.
  * HRT_FLAG_GAMMA is ignored here; hrt_finalize_tiles applies it. */
-int hrt_render_accumulate(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
+HRT_API int hrt_render_accumulate(hrt_scene *scene, const hrt_camera *cam, uint32_t w, uint32_t h,
                           uint32_t first_sample, uint32_t n_samples, uint64_t seed, uint32_t flags,
                           uint32_t rank, uint32_t world, float *d_sum_tiles, void *stream);
 /* sums -> pixel means (`image[i] /= nsamples`, main.cpp:195) and, with HRT_FLAG_GAMMA, gamma_correct
  * (main.cpp:196).  d_tiles may alias d_sum_tiles.  The result is what hrt_render_tiles(total_samples) writes. */
-int hrt_finalize_tiles(const float *d_sum_tiles, uint32_t n_tiles, uint32_t total_samples, uint32_t flags,
+HRT_API int hrt_finalize_tiles(const float *d_sum_tiles, uint32_t n_tiles, uint32_t total_samples, uint32_t flags,
                        float *d_tiles, void *stream);
 /* The PPM file of main.cpp:252-262 encoded ON THE DEVICE from a row-major frame (device, h*w*3 floats).
  * format 3: the reference's ASCII file byte for byte ("P3\n<w> <h>\n255\n", then "r g b " per pixel, "\n");
  * format 6: the same integers as bytes (binary PPM; negative values, which P3 prints with a sign, clamp to 0).
  * d_out: device buffer of `capacity` bytes (16*w*h + 64 always suffices for non-negative frames; the call
  * fails with the needed size otherwise); *bytes = size of the file.  Synchronises the stream. */
-int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, unsigned char *d_out,
+HRT_API int hrt_encode_ppm(const float *d_frame, uint32_t w, uint32_t h, int format, unsigned char *d_out,
                    size_t capacity, size_t *bytes, void *stream);
 
 #ifdef __cplusplus

@@ -53,6 +53,10 @@ def test_c_abi_exports_every_declared_symbol(hrt):
         assert hasattr(dev, n), f"libhrt.so does not export {n}"
     for n in host_names:
         assert hasattr(host, n), f"libhrt_host.so does not export {n}"
+    # ... and nothing else: libhrt.so is linked with a version script written from the header (no kernel handles, no C++ internals)
+    nm = subprocess.run(["nm", "-D", "--defined-only", dev._name], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in nm.splitlines() if line.strip())
+    assert exported == dev_names, f"libhrt.so exports {sorted(set(exported) ^ set(dev_names))} beyond / short of include/hrt.h"
 
 
 def test_device_library_fails_loudly_without_init(hrt):
