@@ -403,6 +403,23 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     }
     std::vector<float4> qfilter;
     build_quad_filter(quads, D.n_quads, qfilter, s->d.qf_n);
+    std::vector<float4> sfilter;  // hrt_device.h DScene::sfilter; hrt_kernels.hip sphere_filter
+    {
+        const uint32_t ns = D.n_spheres, pairs = (ns + 1u) / 2u;
+        bool moving = false;
+        for (uint32_t p = 0; p < pairs; ++p) {
+            const uint32_t a = 2u * p, b = std::min(2u * p + 1u, ns - 1u);
+            const float4 a0 = spheres[2u * a], a1 = spheres[2u * a + 1u], b0 = spheres[2u * b], b1 = spheres[2u * b + 1u];
+            sfilter.push_back(make_float4(a0.x, b0.x, a0.y, b0.y));
+            sfilter.push_back(make_float4(a0.z, b0.z, a0.w * a0.w, b0.w * b0.w));
+            sfilter.push_back(make_float4(a1.x, b1.x, a1.y, b1.y));
+            sfilter.push_back(make_float4(a1.z, b1.z, 0.f, 0.f));
+            moving = moving || a1.x != 0.f || a1.y != 0.f || a1.z != 0.f || b1.x != 0.f || b1.y != 0.f || b1.z != 0.f;
+        }
+        s->d.sf_pairs = pairs;
+        s->d.sf_psize = std::max(1u, (pairs + 63u) / 64u);
+        s->d.sf_moving = moving ? 1u : 0u;
+    }
     for (uint32_t i = 0; i < D.n_lights; ++i) {
         const hrt_light &l = D.lights[i];
         lights.push_back(make_float4(l.pos[0], l.pos[1], l.pos[2], l.radius));
@@ -758,6 +775,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         d.meshes = reinterpret_cast<const DMesh *>(d.tabs + d.tab_meshes);
     }
     UP(qfilter, qfilter, float4)
+    UP(sfilter, sfilter, float4)
     UP(units, kd_units, uint4)
     UP(tris, tris, float4)
     UP(planes, tri_planes, float4)

@@ -657,6 +657,80 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsu
     return cand;
 }
 
+// FILTER over the spheres of a scene that has many (wave-uniform loop, scalar rows, no square root, no division): bit g of the
+// result = some sphere of pair group g (DScene::sf_psize consecutive PAIRS of spheres) can possibly give Sphere::intersect an
+// accepted hit; prims_hit then runs the exact arithmetic only on those, per lane, in index order.  Two spheres A, B go through
+// every instruction together: the rows hold (A, B) register pairs and the arithmetic is written on two-element vectors, which
+// gfx950 executes as v_pk_add / v_pk_mul / v_pk_fma_f32 (one issue slot for both).  For the ray o + t d and the sphere centre
+// c = c0 + time * motion the exact test (sphere_t) forms  oc = o - c,  b = 2 d.oc,  cc = oc.oc - r^2,  delta = b^2 - 4 a cc
+// and has NO accepted hit when delta < 0 or when b >= 0 (then t = (-b - sqrt(delta)) / 2a <= 0 fails `t >= EPSILON`).  The
+// filter evaluates the same quantities with fused multiply-adds,
+//     bh = d.oc     S = oc.oc     E1 = bh^2 - a (S - r^2) + m     E3 = mb - bh |bh|
+// and keeps the sphere when E1 >= 0 and E3 >= 0, where the margins bound everything that can differ between the two
+// evaluations.  Both compute oc to within 0.35 e, e = err_abs = 2e-6 ext (ext = extent of scene and camera; three roundings of
+// a coordinate are 1.8e-7 ext per component).  delta / 4 = bh^2 - a cc has gradient <= 4 sqrt(S) in oc, so the two values
+// differ by <= 4 sqrt(S) e <= 2 e (S / L + L) for any L > 0; with L = ext / 4 that is 1.6e-5 S + 1e-6 ext^2.  The roundings
+// of the products and sums add <= 1e-6 (S + r^2) on either side.  Hence
+//     m = 2.6e-5 (S + r^2) + 2.5e5 e^2 + 1e-30          mb = 2 e^2 + 1e-12 S  >=  (e + 2e-7 sqrt(S))^2  >=  |bh - b/2|^2.
+// (A ray that starts inside a sphere -- cc < 0 -- is not rejected here; the exact test sends it away.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk(float x) { v2f r; r.x = x; r.y = x; return r; }
+__device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#ifndef HRT_SPHERE_FILTER_MIN
+#define HRT_SPHERE_FILTER_MIN 8u  // fewer spheres go through the exact test directly (the two of the Cornell box)
+#endif
+template <class CX>
+__device__ __forceinline__ uint64_t sphere_filter(const CX &cx, const Ray &ray) {
+    cscene S = cx.S;
+    cf4 rows = (cf4)S->sfilter;
+    const uint32_t pairs = S->sf_pairs, psize = S->sf_psize;
+    const float e = cx.err_abs, km = 2.6e-5f;
+    const float a = dot(ray.d, ray.d);
+    const v2f ox = pk(ray.o.x), oy = pk(ray.o.y), oz = pk(ray.o.z), dx = pk(ray.d.x), dy = pk(ray.d.y), dz = pk(ray.d.z);
+    const v2f ntime = pk(-ray.time), a_lo = pk(-(a - km)), a_hi = pk(a + km), m_abs = pk(2.5e5f * e * e + 1e-30f), k12 = pk(1e-12f);
+    const float mb0 = -(2.f * e * e);
+    uint32_t lo = 0u, hi = 0u;
+    auto test = [&](const float4 &r0, const float4 &r1, const float4 &r2, const float4 &r3, uint32_t bit_lo, uint32_t bit_hi) {
+        v2f cx_, cy_, cz_, r2_, mx_, my_, mz_;
+        cx_.x = r0.x; cx_.y = r0.y; cy_.x = r0.z; cy_.y = r0.w; cz_.x = r1.x; cz_.y = r1.y; r2_.x = r1.z; r2_.y = r1.w;
+        mx_.x = r2.x; mx_.y = r2.y; my_.x = r2.z; my_.y = r2.w; mz_.x = r3.x; mz_.y = r3.y;
+        // (always: a static sphere has motion 0 and x - 0 * time == x; a uniform branch here became six selects)
+        const v2f x = pkfma(mx_, ntime, ox - cx_), y = pkfma(my_, ntime, oy - cy_), z = pkfma(mz_, ntime, oz - cz_);
+        const v2f bh = pkfma(dz, z, pkfma(dy, y, dx * x));
+        const v2f S2 = pkfma(z, z, pkfma(y, y, x * x));
+        const v2f e1 = pkfma(a_hi, r2_, pkfma(a_lo, S2, pkfma(bh, bh, m_abs)));
+        v2f w;
+        w.x = __builtin_fmaf(bh.x, fabsf(bh.x), mb0); w.y = __builtin_fmaf(bh.y, fabsf(bh.y), mb0);
+        const v2f e3 = pkfma(S2, k12, -w);
+        const bool keep = (fminf(e1.x, e3.x) >= 0.f) | (fminf(e1.y, e3.y) >= 0.f);
+        if (keep) { lo |= bit_lo; hi |= bit_hi; }
+    };
+    // Two row sets in ping-pong, as in quad_filter: the scalar loads of the next pair overlap the arithmetic of this one.
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    float4 a0 = z4, a1 = z4, a2 = z4, a3 = z4, b0 = z4, b1 = z4, b2 = z4, b3 = z4;
+    auto fetch = [&](uint32_t p, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
+        q0 = ld(rows, 4u * p); q1 = ld(rows, 4u * p + 1u); q2 = ld(rows, 4u * p + 2u); q3 = ld(rows, 4u * p + 3u);
+    };
+    auto bits = [&](uint32_t p, uint32_t &bl, uint32_t &bh_) {
+        const uint32_t g = p / psize;
+        bl = g < 32u ? 1u << g : 0u; bh_ = g >= 32u ? 1u << (g - 32u) : 0u;
+    };
+    if (pairs > 0u) fetch(0u, a0, a1, a2, a3);
+    if (pairs > 1u) fetch(1u, b0, b1, b2, b3);
+    for (uint32_t p = 0; p < pairs; p += 2u) {
+        uint32_t bl, bh_;
+        bits(p, bl, bh_);
+        test(a0, a1, a2, a3, bl, bh_);
+        if (p + 2u < pairs) fetch(p + 2u, a0, a1, a2, a3);
+        if (p + 1u < pairs) {
+            bits(p + 1u, bl, bh_);
+            test(b0, b1, b2, b3, bl, bh_);
+            if (p + 3u < pairs) fetch(p + 3u, b0, b1, b2, b3);
+        }
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // Spheres then squares of Scene::computeIntersection (Scene.h:207-221).
 template <class CX>
 __device__ __forceinline__ Hit prims_hit(const CX &cx, const Ray &ray) {
@@ -665,9 +739,25 @@ __device__ __forceinline__ Hit prims_hit(const CX &cx, const Ray &ray) {
     h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
     cf4 sph = (cf4)S->spheres;
     const uint32_t ns = S->n_spheres;
-    for (uint32_t i = 0; i < ns; ++i) {
-        float t;
-        if (sphere_t(ld(sph, 2 * i), ld(sph, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
+    if (!CX::exact && ns >= HRT_SPHERE_FILTER_MIN) {
+        // FILTER (sphere_filter, above), then REFINE: every lane takes the spheres of ITS candidate groups through the exact
+        // arithmetic, in index order with the reference's strict `<` (Scene.h:207-213), rows fetched per lane.
+        uint64_t cand = sphere_filter(cx, ray);
+        const uint32_t gs = 2u * S->sf_psize;  // spheres per group
+        const typename CX::tab4 rows = cx.ts;
+        while (cand) {
+            const uint32_t i0 = (uint32_t)__builtin_ctzll(cand) * gs, i1 = min(i0 + gs, ns);
+            cand &= cand - 1ull;
+            for (uint32_t i = i0; i < i1; ++i) {
+                float t;
+                if (sphere_t(ld(rows, 2 * i), ld(rows, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
+            }
+        }
+    } else {
+        for (uint32_t i = 0; i < ns; ++i) {
+            float t;
+            if (sphere_t(ld(sph, 2 * i), ld(sph, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
+        }
     }
     STAMP(1);
     cf4 qd = (cf4)S->quads;

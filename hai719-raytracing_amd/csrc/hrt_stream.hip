@@ -306,11 +306,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #define SP_UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 #ifndef HRT_SP_SEG_KIND
-#define HRT_SP_SEG_KIND 1  // which chunk class the diagnostic build stamps: 1 square hits, 2 T (KD walk)
+#define HRT_SP_SEG_KIND 1  // which chunk class the diagnostic build stamps: 1 square hits, 2 T (KD walk), 3 sphere hits, 4 G (new paths), 5 mesh hits
 #endif
 #ifdef HRT_SP_SEG  // diagnostic build: where a square-hit chunk spends its clocks; every stamp first drains the wave's memory
                    // counters, so segments are serialised and the whole run is slower than the shipped kernel
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
+    unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, seg_last = 0;
     bool seg_on = false;
 #define SEG_START(on) do { seg_on = (on); if (seg_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); seg_last = __builtin_readcyclecounter(); } } while (0)
 #define SEG(k) do { if (seg_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
@@ -648,7 +648,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 bool trace = false, freed = false;  // trace: the path has a new ray to intersect; freed: its path has ended (unit fin_unit)
                 bool ended = false, last_seg = false;  // ended: the sample's colour `rad` is final; last_seg: the new ray is the path's last segment
                 f3 rad = mk(0.f, 0.f, 0.f);
-                SEG_START(HRT_SP_SEG_KIND == 1 && !is_gen && c >= e1 && c < e2);  // square-hit chunks
+                SEG_START((HRT_SP_SEG_KIND == 1 && !is_gen && c >= e1 && c < e2) || (HRT_SP_SEG_KIND == 3 && !is_gen && c >= e3 && c < e1) ||
+                          (HRT_SP_SEG_KIND == 4 && is_gen) || (HRT_SP_SEG_KIND == 5 && !is_gen && c < e3));  // the chunk class in hand
                 Ray ray;
                 ray.o = mk(0.f, 0.f, 0.f); ray.d = mk(0.f, 0.f, 1.f); ray.time = 0.f;
                 if (act && is_gen) {
@@ -703,6 +704,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         SEG(1);  // shade: material rows, texel, normal map
                         f3 direct = mk(0.f, 0.f, 0.f);
                         if (LIGHTS) direct = direct_light(cx, sf, ray, rng);
+                        SEG(8);  // direct light (shadow rays)
                         rad = rad + thr * (direct + sf.emission);
                         thr = thr * sf.albedo;
                         scatter(sf, ray, rng);
@@ -797,7 +799,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 
 #ifdef HRT_SP_SEG
     if (lane == 0 && R.stamps)
-        for (int k = 0; k < 8; ++k) atomicAdd(R.stamps + k, seg[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(R.stamps + k, seg[k]);
 #endif
 #ifdef HRT_WALK_SEG  // diagnostic build: where the trips of the KD walk spend their clocks (hrt_dual.hip mesh_walk)
     if (lane == 0 && R.stamps)

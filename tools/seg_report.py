@@ -18,8 +18,9 @@ if os.environ.get("HRT_SEG_KIND") == "2":  # T chunks
     for k, nm in enumerate(["record load", "walk (6 trips)", "stores + appends"]):
         print(f"  {nm:32s} {out[k] / n:8.0f} clocks  {100.0 * out[k] / max(1, tot):5.1f} %")
 else:
-    names = ["record load", "shade (mat rows, texel, nmap)", "scatter", "write-back / sample store", "spheres + squares", "mesh gates", "stores + appends"]
-    tot = sum(out[:7])
-    print(f"{name} {w}x{h}@{spp}: kernel {st.kernel_ms:.1f} ms, {n} square-hit chunks, {tot / n:.0f} clocks per chunk")
+    names = ["record load / camera ray", "shade (mat rows, texel, nmap)", "scatter", "write-back", "spheres + squares", "mesh gates", "sample store + stores + appends", None, "direct light (shadow rays)"]
+    tot = sum(out[:7]) + out[8]
+    kind = {"1": "square-hit", "3": "sphere-hit", "4": "G (new path)", "5": "mesh-hit"}.get(os.environ.get("HRT_SEG_KIND", "1"), "?")
+    print(f"{name} {w}x{h}@{spp}: kernel {st.kernel_ms:.1f} ms, {n} {kind} chunks, {tot / n:.0f} clocks per chunk")
     for k, nm in enumerate(names):
-        print(f"  {nm:32s} {out[k] / n:8.0f} clocks  {100.0 * out[k] / max(1, tot):5.1f} %")
+        if nm: print(f"  {nm:32s} {out[k] / n:8.0f} clocks  {100.0 * out[k] / max(1, tot):5.1f} %")
