@@ -16,12 +16,13 @@ samples per pixel grow as 256*N so every GPU traces the same 530.8 M samples as 
 (HRT_BENCH_SHARE_GPU=1 rehearses the N > 1 path on a one-GPU box: all ranks share GPU 0, collectives over gloo.)
 
 Rank 0 prints ONE JSON line.  What its evidence keys mean:
-  roofline      memory side of the dominant kernel.  `traffic` = bytes per launch that crossed the L2 <-> fabric boundary,
-                (FETCH_SIZE x 2 + WRITE_SIZE) from the committed rocprofv3 PMC passes of THIS build (profiles/, separate
-                --pmc runs, gfx950 correction of MI355X_MICROARCH.md 'HBM'); Infinity-Cache hits are in that count, so it
-                is an UPPER bound on HBM bytes.  achieved = traffic / the kernel's launch duration measured live here with
-                HIP events on the launch stream; frac = achieved / 8 TB/s and cannot exceed 1 by construction of the
-                counters.  `algorithmic` keeps SURVEY 8(d)'s convention (fixed record sizes x per-sample work counters)
+  roofline      memory side of the dominant kernel.  `traffic` = bytes per launch that crossed the L2 <-> fabric boundary, from
+                the committed rocprofv3 PMC passes (profiles/r03_<cfg>_pmc.json; separate --pmc runs): read and write requests
+                by size (TCC_EA0_RDREQ_32B / _64B / _128B, WRREQ_64B / others), checked against a known byte count on the path
+                pool's own access pattern (profiles/r03_traffic_calibration.json).  The summary carries the hash of the kernel
+                sources it was measured on: a build with another hash gets traffic = null (never a stale number).
+                Infinity-Cache hits are in that count, so it is an UPPER bound on HBM bytes.  achieved = traffic / the
+                kernel's launch duration measured live here with HIP events on the launch stream; frac = achieved / 8 TB/s.  `algorithmic` keeps SURVEY 8(d)'s convention (fixed record sizes x per-sample work counters)
                 as information only: those records are served from SGPRs, LDS and L2, not from HBM.
   valu          the bound that actually binds: SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES summed over SIMDs), i.e. the share
                 of SIMD cycles that issued vector work, with the lane utilisation of that work beside it (same PMC runs).
@@ -31,6 +32,8 @@ Rank 0 prints ONE JSON line.  What its evidence keys mean:
                 bounded sample of the same workload, threaded three ways -- a reported baseline, not the target.
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
@@ -57,33 +60,63 @@ def algorithmic_bytes_per_sample(w, h, spp):
     return b + 12.0 / spp, c
 
 
-def committed_pmc():
-    """Counters of the trace kernel for this workload from the committed rocprofv3 PMC summary of this build
-    (profiles/r02_pmc.json, written by tools/profile.sh + tools/pmc_summary.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PROFILE_TAG = "r03"
+
+
+def source_sha16():
+    """Hash of everything libhrt.so is compiled from (the same function is in tools/pmc_summary.py)."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "hai719-raytracing_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "hrt.h"),
+                                                                                          os.path.join(ROOT, "hai719-raytracing_amd", "Makefile")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_pmc(cfg, scene, w, h, spp):
+    """(summary, note): counters of the trace kernel for this configuration from the committed rocprofv3 PMC summary
+    (profiles/r03_<cfg>_pmc.json, written by tools/profile.sh + tools/pmc_summary.py) -- only when it was measured on the
+    sources this build is compiled from; otherwise (None, why)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{cfg}_pmc.json")
     if not os.path.exists(path):
-        return None
+        return None, f"no profiles/{PROFILE_TAG}_{cfg}_pmc.json"
     with open(path) as f:
         j = json.load(f)
-    return j if j.get("config", "").startswith(f"{SCENE} {W}x{H}@{SPP}") else None
+    if (j.get("scene"), j.get("w"), j.get("h"), j.get("spp")) != (scene, w, h, spp):
+        return None, "the committed profile is of another workload"
+    sha = source_sha16()
+    if j.get("source_sha16") != sha:
+        return None, f"the committed profile was measured on kernel sources {j.get('source_sha16')}, this build is {sha}: re-run tools/profile.sh"
+    return j, None
+
+
+def valu_of(pmc):
+    d = pmc["derived"]
+    return {"active_simd_cycles": d["valu_active_simd_cycles"], "peak_simd_cycles": d["simd_cycles"], "frac": d["valu_busy_frac"],
+            "lane_utilisation": d["valu_lane_utilisation"], "valu_wave_insts_per_sample": d["valu_wave_insts_per_sample"],
+            "note": "SQ_ACTIVE_INST_VALU over SQ_BUSY_CYCLES x SIMDs (quad-cycles both), same rocprofv3 PMC runs as traffic"}
 
 
 def cpu_baseline(hrt, desc, cam):
     """The oracle on a bounded sample, ~8 s per leg: (1) a pool of hardware_concurrency threads over scanlines with
     per-path random streams -- the `value`; (2) one std::thread per scanline, all spawned at once, as the reference does
     (main.cpp:232-238); (3) the pool drawing every random number from ONE shared generator, the reference's
-    random_float() (Functions.cpp:4-8; mutex-protected here, a data race there)."""
+    random_float() (Functions.cpp:4-8; mutex-protected here, a data race there).  The sample is the WHOLE 1920 x 1080 frame at
+    fewer samples per pixel: the work items are scanlines (as in the reference), and 1080 of them over the host's threads
+    leaves no leg bound by its tail (a 270-line sample gave 256 threads one line each and 14 of them two)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    w, h = 480, 270  # bounded sample of the same scene / camera / seed
+    w, h = W, H  # the frame of the metric, same scene / camera / seed; bounded through the samples per pixel
     threads = os.cpu_count() or 1
     scene = oracle_lib.OracleScene(desc, oracle_lib.MESH_REF_TREE)
-    scene.render(cam, w, h, 2, seed=SEED, threads=threads)  # page the scene in, start the thread pool once
+    scene.render(cam, w, h, 1, seed=SEED, threads=threads)  # page the scene in, start the thread pool once
     t0 = time.perf_counter()
-    scene.render(cam, w, h, 16, seed=SEED, threads=threads)  # calibration
-    rate = w * h * 16 / max(time.perf_counter() - t0, 1e-3)
-    spp = int(min(1024, max(4, 8.0 * rate / (w * h))))
+    scene.render(cam, w, h, 1, seed=SEED, threads=threads)  # calibration
+    rate = w * h / max(time.perf_counter() - t0, 1e-3)
+    spp = int(min(256, max(1, 8.0 * rate / (w * h))))
 
     def leg(nthreads, flags, spp_):
         t0 = time.perf_counter()
@@ -102,7 +135,7 @@ def cpu_baseline(hrt, desc, cam):
     return {
         "value": pool, "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": f"{SCENE} {w}x{h}@{spp} spp, same camera and seed, oracle (reference-shaped KD-tree), "
-                  f"{threads} threads over scanlines, {dt_pool} s",
+                  f"{h} scanline work items over {threads} threads ({h / threads:.1f} per thread), {dt_pool} s",
         "thread_per_scanline": {"value": per_line, "threads": h, "seconds": dt_line,
                                 "note": "one std::thread per scanline, all started at once (main.cpp:232-238)"},
         "shared_rng": {"value": shared, "threads": shared_threads, "spp": shared_spp, "seconds": dt_shared,
@@ -114,16 +147,50 @@ OTHER_CONFIGS = [("cfg1", "cornell_box", 256, 256, 4), ("cfg2", "cornell_mesh", 
                  ("cfg4", "mesh_in_box", 3840, 2160, 512), ("cfg5", "backrooms_pool", 3840, 2160, 1024)]
 
 
+def frame_mean(img):
+    """Mean of a frame in float64 over the float32 pixels: pixels are deterministic (keyed random streams, ordered sums), so this
+    number is too, and tests/golden/bench_frame_means.json holds it for every configuration bench.py times."""
+    import numpy as np
+    return float(np.asarray(img, dtype=np.float64).mean())
+
+
+def committed_frame_means():
+    path = os.path.join(ROOT, "tests", "golden", "bench_frame_means.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
 def other_configs(hrt):
-    """Kernel time of BASELINE.json's other configurations at their true sizes on this GPU: one launch each (~12 s)."""
+    """Kernel time of BASELINE.json's other configurations at their true sizes on this GPU: one launch each (~12 s).  What is
+    timed is also CHECKED: every frame must be finite and its mean must equal the committed one exactly (tolerance 0)."""
+    import numpy as np
     out = {}
+    means = committed_frame_means()
     for tag, name, w, h, spp in OTHER_CONFIGS:
         dev = hrt.DeviceScene(hrt.HostScene().setup(name, w / h, 1).flatten())
         cam = hrt.default_camera(w / h)
         dev.render(cam, 64, 64, 1, SEED)  # first-launch costs out of the way
-        _, st = dev.render(cam, w, h, spp, SEED)
+        img, st = dev.render(cam, w, h, spp, SEED)
+        if not np.isfinite(img).all():
+            raise SystemExit(f"bench.py: {tag} ({name} {w}x{h}@{spp}) rendered non-finite pixels")
+        mean = frame_mean(img)
+        key = f"{name} {w}x{h}@{spp} seed {SEED}"
+        if key in means and means[key] != mean:
+            raise SystemExit(f"bench.py: {tag}: frame mean {mean!r} differs from the committed {means[key]!r} ({key})")
         out[tag] = {"scene": name, "size": f"{w}x{h}@{spp}", "kernel_ms": round(st.kernel_ms, 2),
-                    "msamples_per_s": round(w * h * spp / st.kernel_ms / 1e3, 1)}
+                    "msamples_per_s": round(w * h * spp / st.kernel_ms / 1e3, 1), "frame_mean": mean,
+                    "frame_mean_checked": key in means}
+        pmc, why = committed_pmc(tag, name, w, h, spp)
+        if pmc:
+            d = pmc["derived"]
+            out[tag]["valu"] = {k: valu_of(pmc)[k] for k in ("frac", "lane_utilisation", "valu_wave_insts_per_sample")}
+            if "fabric_bytes_per_launch" in d:
+                out[tag]["fabric_frac_of_hbm_peak"] = round(d["fabric_bytes_per_launch"] / (st.kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+            out[tag]["kernel"] = pmc["kernel"]
+        else:
+            out[tag]["profile"] = why
         dev.close()
     return out
 
@@ -206,26 +273,22 @@ def main():
         bps, counts = algorithmic_bytes_per_sample(W, H, spp)
         launch_samples = W * H * spp / world  # what ONE launch (this rank's tiles) traces
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-        pmc = committed_pmc() if (world == 1 and args.spp == SPP) else None
-        traffic = pmc["derived"]["fabric_bytes_per_launch"] if pmc else None
+        pmc, pmc_note = committed_pmc("cfg2_256", SCENE, W, H, SPP) if (world == 1 and args.spp == SPP) else (None, "profiles are of the 1-GPU metric line")
+        traffic = pmc["derived"].get("fabric_bytes_per_launch") if pmc else None
         achieved = traffic / avg_kernel_s / 1e9 if traffic else None
         roofline = {
             "bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": None if not pmc else pmc["source"],
+            "traffic_source": pmc_note if not pmc else pmc["source"],
+            "traffic_calibration": None if not pmc else {"fetch_factor": pmc["derived"].get("fetch_factor"), "write_factor": pmc["derived"].get("write_factor"),
+                                                       "see": f"profiles/{PROFILE_TAG}_traffic_calibration.json"},
             "algorithmic": {"bytes_per_sample": round(bps, 1), "bytes_per_launch": round(bps * launch_samples),
                             "gbps": round(bps * launch_samples / avg_kernel_s / 1e9, 1),
                             "note": "SURVEY 8(d) convention (record sizes x work counters): served from SGPRs / LDS / L2, not a bandwidth"},
-            "note": "achieved = L2<->fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included: an upper "
+            "note": "achieved = L2<->fabric bytes per launch (requests by size, Infinity-Cache hits included: an upper "
                     "bound on HBM bytes) / the kernel's live HIP-event time; the kernel is VALU / latency bound, see valu",
         }
-        valu = None
-        if pmc:
-            d = pmc["derived"]
-            valu = {"active_simd_cycles": d["valu_active_simd_cycles"], "peak_simd_cycles": d["simd_cycles"],
-                    "frac": d["valu_busy_frac"], "lane_utilisation": d["valu_lane_utilisation"],
-                    "valu_wave_insts_per_sample": d["valu_wave_insts_per_sample"],
-                    "note": "SQ_ACTIVE_INST_VALU over SQ_BUSY_CYCLES x SIMDs (quad-cycles both), same rocprofv3 PMC runs as traffic"}
+        valu = valu_of(pmc) if pmc else None
         out = {
             "metric": "Msamples/s (pixels x spp / s), Cornell+mesh 1080p@256spp",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,8 +300,18 @@ def main():
             "kernel_ms_per_launch": round(avg_kernel_s * 1e3, 3),
             "roofline": roofline, "valu": valu,
         }
+        out["source_sha16"] = source_sha16()
         if frame is not None:
-            out["frame_mean"] = round(float(frame.mean().item()), 6)
+            import numpy as np
+            host_frame = frame.cpu().numpy()
+            if not np.isfinite(host_frame).all():
+                raise SystemExit("bench.py: the timed frame has non-finite pixels")
+            out["frame_mean"] = frame_mean(host_frame)
+            key = f"{SCENE} {W}x{H}@{spp} seed {SEED}"
+            means = committed_frame_means()
+            if key in means and means[key] != out["frame_mean"]:
+                raise SystemExit(f"bench.py: frame mean {out['frame_mean']!r} differs from the committed {means[key]!r} ({key})")
+            out["frame_mean_checked"] = key in means
         if world == 1 and not args.no_extras:
             import numpy as np
             host_img, st = scene.render(cam, W, H, spp, SEED, flags=hrt.FLAG_GAMMA)  # once to size the library's buffers

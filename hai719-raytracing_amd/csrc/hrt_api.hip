@@ -311,6 +311,8 @@ int hrt_init(int device_ordinal) {
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_exact, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights_exact, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_sph, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)hrt_wgstream_kernel_lights_sph, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const char *k = std::getenv("HRT_KERNEL");
         const std::string ks = k ? k : "";
         g_rt.use_dual = ks != "single";
@@ -406,19 +408,16 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
     std::vector<float4> sfilter;  // hrt_device.h DScene::sfilter; hrt_kernels.hip sphere_filter
     {
         const uint32_t ns = D.n_spheres, pairs = (ns + 1u) / 2u;
-        bool moving = false;
         for (uint32_t p = 0; p < pairs; ++p) {
             const uint32_t a = 2u * p, b = std::min(2u * p + 1u, ns - 1u);
             const float4 a0 = spheres[2u * a], a1 = spheres[2u * a + 1u], b0 = spheres[2u * b], b1 = spheres[2u * b + 1u];
             sfilter.push_back(make_float4(a0.x, b0.x, a0.y, b0.y));
             sfilter.push_back(make_float4(a0.z, b0.z, a0.w * a0.w, b0.w * b0.w));
             sfilter.push_back(make_float4(a1.x, b1.x, a1.y, b1.y));
-            sfilter.push_back(make_float4(a1.z, b1.z, 0.f, 0.f));
-            moving = moving || a1.x != 0.f || a1.y != 0.f || a1.z != 0.f || b1.x != 0.f || b1.y != 0.f || b1.z != 0.f;
+            sfilter.push_back(make_float4(a1.z, b1.z, std::fabs(a0.w), std::fabs(b0.w)));
         }
         s->d.sf_pairs = pairs;
         s->d.sf_psize = std::max(1u, (pairs + 63u) / 64u);
-        s->d.sf_moving = moving ? 1u : 0u;
     }
     for (uint32_t i = 0; i < D.n_lights; ++i) {
         const hrt_light &l = D.lights[i];
@@ -490,7 +489,8 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         //   a walk then descends two levels per round trip (csrc/hrt_kernels.hip kd_descend);
         //   leaves keep their four units {lo, first} {hi, count} {ropes -x +x -y +y} {ropes -z +z}, refs translated, on 64-byte lines.
         // Numbering is breadth-first from the root, so a prefix of the array is the top of the tree (what the kernels stage in LDS).
-        // Only reachable, well-formed nodelets are accepted.
+        // Only well-formed nodelets the ROOT reaches through child links are accepted, as what they are: a rope, too, may only name
+        // such a nodelet, with its own kind (an inner unit named as a leaf would be read as four units from a two-unit slot).
         auto in_range = [&](uint32_t ref) -> bool {
             if (ref == HRT_KD_NIL) return true;
             const uint32_t idx = ref & ~HRT_KD_LEAF;
@@ -498,11 +498,11 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         };
         if (M.n_leaf_tris) {
             if (M.kd_root == HRT_KD_NIL || !in_range(M.kd_root)) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree");
+            std::vector<uint8_t> reached(M.n_kd_units, 0);  // 1: an inner nodelet of the tree, 2: a leaf of the tree
             {   // the child links must form a TREE: a nodelet reached twice (a shared subtree, or a cycle -- on which a walk would
                 // descend forever) is refused
-                std::vector<uint8_t> reached(M.n_kd_units, 0);
                 std::vector<uint32_t> stack{M.kd_root};
-                reached[M.kd_root & ~HRT_KD_LEAF] = 1;
+                reached[M.kd_root & ~HRT_KD_LEAF] = (M.kd_root & HRT_KD_LEAF) ? 2 : 1;
                 while (!stack.empty()) {
                     const uint32_t ref = stack.back();
                     stack.pop_back();
@@ -511,7 +511,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                     for (int c = 2; c < 4; ++c) {
                         const uint32_t child = u.w[c];
                         if (child == HRT_KD_NIL || !in_range(child) || reached[child & ~HRT_KD_LEAF]) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree (a nodelet is reached twice through child links)");
-                        reached[child & ~HRT_KD_LEAF] = 1;
+                        reached[child & ~HRT_KD_LEAF] = (child & HRT_KD_LEAF) ? 2 : 1;
                         stack.push_back(child);
                     }
                 }
@@ -524,6 +524,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 if (ref == HRT_KD_NIL) return;
                 if (!in_range(ref)) { ok = false; return; }
                 const uint32_t idx = ref & ~HRT_KD_LEAF;
+                if (reached[idx] != ((ref & HRT_KD_LEAF) ? 2 : 1)) { ok = false; return; }  // (ropes: child links were checked above)
                 if (new_of[idx] != 0xFFFFFFFFu) return;
                 const uint32_t size = (ref & HRT_KD_LEAF) ? 4u : 2u;
                 cur = (cur + size - 1u) & ~(size - 1u);
@@ -555,7 +556,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                     }
                 }
             }
-            if (!ok) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree");
+            if (!ok) return fail(HRT_ERR_INVALID, "malformed flattened KD-tree (a link or rope names a unit that is not a nodelet of this tree, or not of that kind)");
             auto tr = [&](uint32_t ref) -> uint32_t { return ref == HRT_KD_NIL ? ref : ((new_of[ref & ~HRT_KD_LEAF] + unit_base) | (ref & HRT_KD_LEAF)); };
             units.resize(unit_base + ((cur + 3u) & ~3u), make_uint4(0, 0, 0, 0));
             for (uint32_t ref : order) {
@@ -764,6 +765,8 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         d.tab_meshes = (uint32_t)tabs.size();
         tabs.resize(tabs.size() + meshes.size() * (sizeof(DMesh) / sizeof(float4)));
         if (!meshes.empty()) std::memcpy(&tabs[d.tab_meshes], meshes.data(), meshes.size() * sizeof(DMesh));
+        d.tab_sfilter = (uint32_t)tabs.size();
+        tabs.insert(tabs.end(), sfilter.begin(), sfilter.end());
         d.tab_exc = (uint32_t)tabs.size();
         d.exc_in_tabs = exceptions.size() <= 1536u ? 1u : 0u;  // short exception lists ride along (24 KB at most)
         if (d.exc_in_tabs) tabs.insert(tabs.end(), exceptions.begin(), exceptions.end());
@@ -775,7 +778,6 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         d.meshes = reinterpret_cast<const DMesh *>(d.tabs + d.tab_meshes);
     }
     UP(qfilter, qfilter, float4)
-    UP(sfilter, sfilter, float4)
     UP(units, kd_units, uint4)
     UP(tris, tris, float4)
     UP(planes, tri_planes, float4)
@@ -1052,6 +1054,9 @@ static int launch_trace(hrt_scene *s, const hrt_camera *cam, uint32_t w, uint32_
     if (stream_kernel && exact) {
         if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights_exact, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
         else hipLaunchKernelGGL(hrt_wgstream_kernel_exact, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+    } else if (stream_kernel && s->d.n_spheres >= HRT_SPHERE_FILTER_MIN && s->d.n_spheres <= 128u) {  // a crowd of spheres: the builds with the pair filter
+        if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights_sph, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
+        else hipLaunchKernelGGL(hrt_wgstream_kernel_sph, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
     } else if (stream_kernel) {
         if (s->d.n_lights) hipLaunchKernelGGL(hrt_wgstream_kernel_lights, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);
         else hipLaunchKernelGGL(hrt_wgstream_kernel, dim3(grid), dim3(HRT_SP_WG), lds_bytes, stream, R);

@@ -72,18 +72,18 @@ struct DScene {
     const DImage *images;
     const uint32_t *texels;
     const float4 *lights;  // 2 rows: {pos.xyz, radius} {color.xyz, 0}
-    const float4 *tabs;        // squares | materials | spheres | mesh records in ONE array (what `quads`, `materials`, `spheres`, `meshes` above
+    const float4 *tabs;        // squares | materials | spheres | mesh records | sphere pair-filter rows (| short exception lists) in ONE array (what `quads`, `materials`, `spheres`, `meshes` above
                                // point into): the streaming kernel stages it in LDS for per-lane row fetches (hrt_kernels.hip CtxT)
     uint32_t tab_quads, tab_mats, tab_spheres, tab_meshes, tab_exc, tab_rows;  // row offsets of the tables, rows in all
     uint32_t exc_in_tabs;      // 1: the meshes' exception lists are short (<= 512 rows) and sit in `tabs` at tab_exc; 0: in `exceptions`
     const float4 *qfilter;     // rows of the squares' no-division filter: squares in an axis plane by normal axis x, y, z (2 rows each), then the rest (4 rows each)
     uint32_t qf_n[4];          // squares per section
-    const float4 *sfilter;     // rows of the spheres' no-square-root filter, 4 per PAIR of spheres (A = 2p, B = 2p + 1; an odd last sphere is
-                               // paired with itself), laid out as the register pairs the packed-fp32 instructions take:
-                               // {c.x A, c.x B, c.y A, c.y B} {c.z A, c.z B, r^2 A, r^2 B} {motion.x A, B, motion.y A, B} {motion.z A, B, -, -}
-    uint32_t sf_pairs;         // pairs in sfilter; sf_psize consecutive pairs share one bit of the filter's 64-bit result
+    uint32_t tab_sfilter;      // row offset in `tabs` of the spheres' pair-filter rows (hrt_kernels.hip sphere_filter), 4 per PAIR of spheres
+                               // (A = 2p, B = 2p + 1; an odd last sphere is paired with itself), laid out as the register pairs the
+                               // packed-fp32 instructions take: {c.x A, c.x B, c.y A, c.y B} {c.z A, c.z B, r^2 A, r^2 B}
+                               // {motion.x A, B, motion.y A, B} {motion.z A, B, |r| A, |r| B}
+    uint32_t sf_pairs;         // pairs; sf_psize consecutive pairs share one bit of the shadow rays' 64-bit group mask
     uint32_t sf_psize;
-    uint32_t sf_moving;        // some sphere moves (rows 2, 3 matter)
     const float4 *exceptions;  // 2 rows per entry (see above)
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
     uint32_t n_kd_units;

@@ -169,19 +169,24 @@ typedef const float __attribute__((address_space(3))) *lf1;
 template <bool LTAB> struct TabPtr { typedef gf4 f4; typedef gmesh mesh; typedef gf1 f1; };
 template <> struct TabPtr<true> { typedef lf4 f4; typedef lmesh mesh; typedef lf1 f1; };
 
-template <bool EXACT, bool LTAB = false>
+// SPHF: the kernel carries the spheres' pair filter (sphere_filter; scenes with HRT_SPHERE_FILTER_MIN..128 spheres run such a
+// build).  It is a build of its own because its code in prims_hit and shadow_blocked costs the register allocator room that
+// the scenes without a crowd of spheres -- every wall-and-mesh scene -- then pay for in spills (measured: Cornell+mesh -17 %).
+template <bool EXACT, bool LTAB = false, bool SPHF = false>
 struct CtxT {
     static constexpr bool exact = EXACT;
+    static constexpr bool sphf = SPHF && !EXACT;
     typedef typename TabPtr<LTAB>::f4 tab4;
     typedef typename TabPtr<LTAB>::mesh tabmesh;
     typename TabPtr<LTAB>::f1 lut;  // the u8 -> float tables (c_u8_lut; staged in LDS beside the tables when LTAB)
     tab4 texc;         // exception lists of the meshes when they are short enough to travel with the tables (DScene::exc_in_tabs)
     tab4 tq, tm, ts;   // per-lane rows of squares (HRT_QUAD_ROWS each), materials (HRT_MAT_ROWS), spheres (HRT_SPHERE_ROWS)
+    tab4 tsf;          // per-lane rows of the spheres' pair filter (4 per pair; sphere_filter reads the same rows wave-uniformly)
     tabmesh tmesh;     // per-lane mesh records
     // the tables live in one array (DScene::tabs) in the order squares, materials, spheres, meshes
     __device__ __forceinline__ void set_tables(tab4 base, typename TabPtr<LTAB>::f1 lut_, cscene S_) {
         lut = lut_;
-        tq = base + S_->tab_quads; tm = base + S_->tab_mats; ts = base + S_->tab_spheres; texc = base + S_->tab_exc;
+        tq = base + S_->tab_quads; tm = base + S_->tab_mats; ts = base + S_->tab_spheres; texc = base + S_->tab_exc; tsf = base + S_->tab_sfilter;
         tmesh = (tabmesh)(base + S_->tab_meshes);
     }
     cscene S;
@@ -657,14 +662,13 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsu
     return cand;
 }
 
-// FILTER over the spheres of a scene that has many (wave-uniform loop, scalar rows, no square root, no division): bit g of the
-// result = some sphere of pair group g (DScene::sf_psize consecutive PAIRS of spheres) can possibly give Sphere::intersect an
-// accepted hit; prims_hit then runs the exact arithmetic only on those, per lane, in index order.  Two spheres A, B go through
-// every instruction together: the rows hold (A, B) register pairs and the arithmetic is written on two-element vectors, which
-// gfx950 executes as v_pk_add / v_pk_mul / v_pk_fma_f32 (one issue slot for both).  For the ray o + t d and the sphere centre
-// c = c0 + time * motion the exact test (sphere_t) forms  oc = o - c,  b = 2 d.oc,  cc = oc.oc - r^2,  delta = b^2 - 4 a cc
-// and has NO accepted hit when delta < 0 or when b >= 0 (then t = (-b - sqrt(delta)) / 2a <= 0 fails `t >= EPSILON`).  The
-// filter evaluates the same quantities with fused multiply-adds,
+// FILTER over the spheres of a scene that has many (no square root, no division): which spheres can possibly give
+// Sphere::intersect an accepted hit; the exact arithmetic (sphere_t) then runs only on those, per lane, in index order.  Two
+// spheres A, B go through every instruction together: the rows hold (A, B) register pairs and the arithmetic is written on
+// two-element vectors, which gfx950 executes as v_pk_add / v_pk_mul / v_pk_fma_f32 (one issue slot for both).  For the ray
+// o + t d and the sphere centre c = c0 + time * motion the exact test forms  oc = o - c,  b = 2 d.oc,  cc = oc.oc - r^2,
+// delta = b^2 - 4 a cc  and has NO accepted hit when delta < 0 or when b >= 0 (then t = (-b - sqrt(delta)) / 2a <= 0 fails
+// `t >= EPSILON`).  The filter evaluates the same quantities with fused multiply-adds,
 //     bh = d.oc     S = oc.oc     E1 = bh^2 - a (S - r^2) + m     E3 = mb - bh |bh|
 // and keeps the sphere when E1 >= 0 and E3 >= 0, where the margins bound everything that can differ between the two
 // evaluations.  Both compute oc to within 0.35 e, e = err_abs = 2e-6 ext (ext = extent of scene and camera; three roundings of
@@ -673,24 +677,25 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsu
 // of the products and sums add <= 1e-6 (S + r^2) on either side.  Hence
 //     m = 2.6e-5 (S + r^2) + 2.5e5 e^2 + 1e-30          mb = 2 e^2 + 1e-12 S  >=  (e + 2e-7 sqrt(S))^2  >=  |bh - b/2|^2.
 // (A ray that starts inside a sphere -- cc < 0 -- is not rejected here; the exact test sends it away.)
+// Rows, 4 per pair (DScene::tab_sfilter): {c.x A, c.x B, c.y A, c.y B} {c.z A, c.z B, r^2 A, r^2 B} {motion.x A, B, motion.y A, B}
+// {motion.z A, B, -, -}; an odd last sphere is paired with itself.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk(float x) { v2f r; r.x = x; r.y = x; return r; }
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 #ifndef HRT_SPHERE_FILTER_MIN
 #define HRT_SPHERE_FILTER_MIN 8u  // fewer spheres go through the exact test directly (the two of the Cornell box)
 #endif
-template <class CX>
-__device__ __forceinline__ uint64_t sphere_filter(const CX &cx, const Ray &ray) {
-    cscene S = cx.S;
-    cf4 rows = (cf4)S->sfilter;
-    const uint32_t pairs = S->sf_pairs, psize = S->sf_psize;
-    const float e = cx.err_abs, km = 2.6e-5f;
-    const float a = dot(ray.d, ray.d);
-    const v2f ox = pk(ray.o.x), oy = pk(ray.o.y), oz = pk(ray.o.z), dx = pk(ray.d.x), dy = pk(ray.d.y), dz = pk(ray.d.z);
-    const v2f ntime = pk(-ray.time), a_lo = pk(-(a - km)), a_hi = pk(a + km), m_abs = pk(2.5e5f * e * e + 1e-30f), k12 = pk(1e-12f);
-    const float mb0 = -(2.f * e * e);
-    uint32_t lo = 0u, hi = 0u;
-    auto test = [&](const float4 &r0, const float4 &r1, const float4 &r2, const float4 &r3, uint32_t bit_lo, uint32_t bit_hi) {
+struct SphereFilterRay {  // what the filter needs of one ray, as (x, x) pairs
+    v2f ox, oy, oz, dx, dy, dz, ntime, a_lo, a_hi, m_abs, k12;
+    float mb0;
+    __device__ __forceinline__ void set(const Ray &ray, float e) {
+        const float a = dot(ray.d, ray.d), km = 2.6e-5f;
+        ox = pk(ray.o.x); oy = pk(ray.o.y); oz = pk(ray.o.z); dx = pk(ray.d.x); dy = pk(ray.d.y); dz = pk(ray.d.z);
+        ntime = pk(-ray.time); a_lo = pk(-(a - km)); a_hi = pk(a + km); m_abs = pk(2.5e5f * e * e + 1e-30f); k12 = pk(1e-12f);
+        mb0 = -(2.f * e * e);
+    }
+    // min(E1, E3) of the pair: sphere A may be hit iff .x >= 0, sphere B iff .y >= 0
+    __device__ __forceinline__ v2f pair(const float4 &r0, const float4 &r1, const float4 &r2, const float4 &r3) const {
         v2f cx_, cy_, cz_, r2_, mx_, my_, mz_;
         cx_.x = r0.x; cx_.y = r0.y; cy_.x = r0.z; cy_.y = r0.w; cz_.x = r1.x; cz_.y = r1.y; r2_.x = r1.z; r2_.y = r1.w;
         mx_.x = r2.x; mx_.y = r2.y; my_.x = r2.z; my_.y = r2.w; mz_.x = r3.x; mz_.y = r3.y;
@@ -702,33 +707,44 @@ __device__ __forceinline__ uint64_t sphere_filter(const CX &cx, const Ray &ray) 
         v2f w;
         w.x = __builtin_fmaf(bh.x, fabsf(bh.x), mb0); w.y = __builtin_fmaf(bh.y, fabsf(bh.y), mb0);
         const v2f e3 = pkfma(S2, k12, -w);
-        const bool keep = (fminf(e1.x, e3.x) >= 0.f) | (fminf(e1.y, e3.y) >= 0.f);
-        if (keep) { lo |= bit_lo; hi |= bit_hi; }
-    };
+        v2f r;
+        r.x = fminf(e1.x, e3.x); r.y = fminf(e1.y, e3.y);
+        return r;
+    }
+};
+// The filter over ALL spheres (wave-uniform loop, scalar rows): bit i of word i / 32 = sphere i may be hit.  Up to 128 spheres.
+template <class CX>
+__device__ __forceinline__ void sphere_filter(const CX &cx, const Ray &ray, uint32_t (&mask)[4]) {
+    cscene S = cx.S;
+    cf4 rows = (cf4)S->tabs + S->tab_sfilter;
+    const uint32_t pairs = S->sf_pairs;
+    SphereFilterRay fr;
+    fr.set(ray, cx.err_abs);
     // Two row sets in ping-pong, as in quad_filter: the scalar loads of the next pair overlap the arithmetic of this one.
     const float4 z4 = make_float4(0, 0, 0, 0);
     float4 a0 = z4, a1 = z4, a2 = z4, a3 = z4, b0 = z4, b1 = z4, b2 = z4, b3 = z4;
     auto fetch = [&](uint32_t p, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
         q0 = ld(rows, 4u * p); q1 = ld(rows, 4u * p + 1u); q2 = ld(rows, 4u * p + 2u); q3 = ld(rows, 4u * p + 3u);
     };
-    auto bits = [&](uint32_t p, uint32_t &bl, uint32_t &bh_) {
-        const uint32_t g = p / psize;
-        bl = g < 32u ? 1u << g : 0u; bh_ = g >= 32u ? 1u << (g - 32u) : 0u;
-    };
     if (pairs > 0u) fetch(0u, a0, a1, a2, a3);
     if (pairs > 1u) fetch(1u, b0, b1, b2, b3);
-    for (uint32_t p = 0; p < pairs; p += 2u) {
-        uint32_t bl, bh_;
-        bits(p, bl, bh_);
-        test(a0, a1, a2, a3, bl, bh_);
-        if (p + 2u < pairs) fetch(p + 2u, a0, a1, a2, a3);
-        if (p + 1u < pairs) {
-            bits(p + 1u, bl, bh_);
-            test(b0, b1, b2, b3, bl, bh_);
-            if (p + 3u < pairs) fetch(p + 3u, b0, b1, b2, b3);
+#pragma unroll
+    for (uint32_t wd = 0; wd < 4u; ++wd) {  // 16 pairs = 32 spheres per mask word
+        uint32_t acc = 0u;
+        const uint32_t p1 = min(16u * wd + 16u, pairs);
+        for (uint32_t p = 16u * wd; p < p1; p += 2u) {
+            const uint32_t bit = 1u << ((2u * p) & 31u);
+            v2f k = fr.pair(a0, a1, a2, a3);
+            acc |= (k.x >= 0.f ? bit : 0u) | (k.y >= 0.f ? bit << 1 : 0u);
+            if (p + 2u < pairs) fetch(p + 2u, a0, a1, a2, a3);
+            if (p + 1u < p1) {
+                k = fr.pair(b0, b1, b2, b3);
+                acc |= (k.x >= 0.f ? bit << 2 : 0u) | (k.y >= 0.f ? bit << 3 : 0u);
+                if (p + 3u < pairs) fetch(p + 3u, b0, b1, b2, b3);
+            }
         }
+        mask[wd] = acc;
     }
-    return ((uint64_t)hi << 32) | lo;
 }
 
 // Spheres then squares of Scene::computeIntersection (Scene.h:207-221).
@@ -739,18 +755,20 @@ __device__ __forceinline__ Hit prims_hit(const CX &cx, const Ray &ray) {
     h.kind = 0; h.index = 0; h.t = HRT_FLT_MAX; h.tri = 0; h.a0 = 0.f; h.a1 = 0.f;
     cf4 sph = (cf4)S->spheres;
     const uint32_t ns = S->n_spheres;
-    if (!CX::exact && ns >= HRT_SPHERE_FILTER_MIN) {
-        // FILTER (sphere_filter, above), then REFINE: every lane takes the spheres of ITS candidate groups through the exact
-        // arithmetic, in index order with the reference's strict `<` (Scene.h:207-213), rows fetched per lane.
-        uint64_t cand = sphere_filter(cx, ray);
-        const uint32_t gs = 2u * S->sf_psize;  // spheres per group
+    if (CX::sphf && ns >= HRT_SPHERE_FILTER_MIN && ns <= 128u) {
+        // FILTER (sphere_filter, above), then REFINE: every lane takes ITS candidate spheres through the exact arithmetic, in
+        // index order with the reference's strict `<` (Scene.h:207-213), rows fetched per lane.
+        uint32_t mask[4];
+        sphere_filter(cx, ray, mask);
         const typename CX::tab4 rows = cx.ts;
-        while (cand) {
-            const uint32_t i0 = (uint32_t)__builtin_ctzll(cand) * gs, i1 = min(i0 + gs, ns);
-            cand &= cand - 1ull;
-            for (uint32_t i = i0; i < i1; ++i) {
+#pragma unroll
+        for (uint32_t wd = 0; wd < 4u; ++wd) {
+            uint32_t cand = mask[wd];
+            while (cand) {
+                const uint32_t i = 32u * wd + (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
                 float t;
-                if (sphere_t(ld(rows, 2 * i), ld(rows, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
+                if (i < ns && sphere_t(ld(rows, 2 * i), ld(rows, 2 * i + 1), ray, t) && t < h.t && HRT_T_ACCEPT(t)) { h.kind = 1; h.index = i; h.t = t; }
             }
         }
     } else {
@@ -849,18 +867,20 @@ __device__ __forceinline__ Hit closest_hit(const CX &cx, const Ray &ray) {
 // Every shadow ray of one shading point runs from p (plus 1e-5 along the ray) to a point within `reach` of the
 // light centre, so it stays inside the capsule of radius `reach` around the segment [p, lpos].  A sphere whose
 // centre is farther than radius + reach from that segment cannot give any of those rays a root, and the
-// reference's loop would skip it without a draw.  Bit g of the result = some sphere of group g (gsize
-// consecutive spheres) may be touched.  The test is a FILTER: its margin covers (a) its own fp32 error
+// reference's loop would skip it without a draw.  Bit g of the result = some sphere of group g (DScene::sf_psize
+// consecutive PAIRS of spheres) may be touched.  The test is a FILTER: its margin covers (a) its own fp32 error
 // (perpendicular-vector form, no cancellation) and (b) the error of the exact test's discriminant, which
-// cancels |oc|^2-sized terms (<= ~1e-6 |oc|^2 absolute; the margin allows 1e-5 |oc|^2).
-__device__ __forceinline__ uint64_t shadow_sphere_groups(cscene S, f3 p, f3 lpos, float reach, float time, uint32_t gsize) {
+// cancels |oc|^2-sized terms (<= ~1e-6 |oc|^2 absolute; the margin allows 1e-5 |oc|^2).  Two spheres per instruction
+// (packed fp32, the pair rows of sphere_filter).
+__device__ __forceinline__ uint64_t shadow_sphere_groups_scalar(cscene S, f3 p, f3 lpos, float reach, float time, uint32_t gsize) {
+    // one sphere at a time, groups of gsize consecutive SPHERES: the kernels without the pair filter (few spheres)
     cf4 sph = (cf4)S->spheres;
     const uint32_t ns = S->n_spheres;
+    uint32_t g = 0, in_group = 0;
     const f3 ax = lpos - p;
     const float len2 = dot(ax, ax);
     const float inv_len2 = len2 > 0.f ? 1.f / len2 : 0.f;
     uint64_t groups = 0ull;
-    uint32_t g = 0, in_group = 0;
     for (uint32_t i = 0; i < ns; ++i) {  // wave-uniform: scalar rows
         const float4 r0 = ld(sph, 2 * i), r1 = ld(sph, 2 * i + 1);
         const f3 v = (mk(r0) + time * mk(r1)) - p;
@@ -873,25 +893,78 @@ __device__ __forceinline__ uint64_t shadow_sphere_groups(cscene S, f3 p, f3 lpos
     }
     return groups;
 }
+__device__ __forceinline__ uint64_t shadow_sphere_groups(cscene S, f3 p, f3 lpos, float reach, float time) {
+    cf4 rows = (cf4)S->tabs + S->tab_sfilter;
+    const uint32_t pairs = S->sf_pairs, psize = S->sf_psize;
+    const f3 ax = lpos - p;
+    const float len2 = dot(ax, ax);
+    const float inv_len2 = len2 > 0.f ? 1.f / len2 : 0.f;
+    const v2f px = pk(p.x), py = pk(p.y), pz = pk(p.z), tm = pk(time), axx = pk(ax.x), axy = pk(ax.y), axz = pk(ax.z);
+    const v2f nax = pk(-ax.x), nay = pk(-ax.y), naz = pk(-ax.z), il2 = pk(inv_len2), rch = pk(reach), c1 = pk(1e-5f * (1.f + len2));
+    uint64_t groups = 0ull;
+    for (uint32_t q = 0; q < pairs; ++q) {  // wave-uniform: scalar rows
+        const float4 r0 = ld(rows, 4u * q), r1 = ld(rows, 4u * q + 1u), r2 = ld(rows, 4u * q + 2u), r3 = ld(rows, 4u * q + 3u);
+        v2f cx_, cy_, cz_, mx_, my_, mz_, rr;
+        cx_.x = r0.x; cx_.y = r0.y; cy_.x = r0.z; cy_.y = r0.w; cz_.x = r1.x; cz_.y = r1.y;
+        mx_.x = r2.x; mx_.y = r2.y; my_.x = r2.z; my_.y = r2.w; mz_.x = r3.x; mz_.y = r3.y; rr.x = r3.z; rr.y = r3.w;
+        const v2f vx = pkfma(mx_, tm, cx_ - px), vy = pkfma(my_, tm, cy_ - py), vz = pkfma(mz_, tm, cz_ - pz);
+        v2f sp = pkfma(vz, axz, pkfma(vy, axy, vx * axx)) * il2;
+        sp.x = fminf(fmaxf(sp.x, 0.f), 1.f); sp.y = fminf(fmaxf(sp.y, 0.f), 1.f);
+        const v2f wx = pkfma(nax, sp, vx), wy = pkfma(nay, sp, vy), wz = pkfma(naz, sp, vz);
+        const v2f ww = pkfma(wz, wz, pkfma(wy, wy, wx * wx)), vv = pkfma(vz, vz, pkfma(vy, vy, vx * vx));
+        const v2f R = rr + rch;
+        const v2f lim = pkfma(R * R, pk(1.01f), pkfma(vv, pk(1e-5f), c1));
+        if ((ww.x <= lim.x) | (ww.y <= lim.y)) groups |= 1ull << (q / psize);
+    }
+    return groups;
+}
 
 // Scene::computeShadow, Scene.h:235-255: candidates in object order, each lets the ray
 // through with probability `transparency` (one draw per candidate).
-// Only the sphere groups in `groups` are tested (shadow_sphere_groups: no other sphere can be reached),
-// in ascending index order, so the draws fall exactly where the reference's full loop puts them.
+// Only the sphere groups in `groups` are tested (shadow_sphere_groups: no other sphere can be reached), in ascending
+// index order, so the draws fall exactly where the reference's full loop puts them; `filter`: the pairs of a group first go
+// through the pair filter of sphere_filter (rows per lane) and only a sphere it keeps through the exact arithmetic.
 template <class CX>
-__device__ __forceinline__ bool shadow_blocked(const CX &cx, const Ray &ray, float tmax, Rng &rng, uint64_t groups, uint32_t gsize) {
+__device__ __forceinline__ bool shadow_blocked(const CX &cx, const Ray &ray, float tmax, Rng &rng, uint64_t groups, bool filter) {
     cscene S = cx.S;
-    const typename CX::tab4 sph = cx.ts, mats = cx.tm;
-    const uint32_t ns = S->n_spheres;
-    while (groups) {
-        const uint32_t i0 = (uint32_t)__builtin_ctzll(groups) * gsize, i1 = min(i0 + gsize, ns);
+    const typename CX::tab4 sph = cx.ts, mats = cx.tm, frows = cx.tsf;
+    const uint32_t ns = S->n_spheres, psize = S->sf_psize, pairs = S->sf_pairs;
+    if (!CX::sphf) {  // groups of gsize consecutive spheres, every one through the exact arithmetic
+        const uint32_t gsize = (ns + 63u) / 64u;
+        while (groups) {
+            const uint32_t i0 = (uint32_t)__builtin_ctzll(groups) * gsize, i1 = min(i0 + gsize, ns);
+            groups &= groups - 1ull;
+            for (uint32_t i = i0; i < i1; ++i) {
+                float t;
+                const float4 r1 = ld(sph, 2 * i + 1);
+                if (sphere_t(ld(sph, 2 * i), r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
+                    const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(r1.w)).w;
+                    if (rng.next() > transparency) return true;
+                }
+            }
+        }
+    }
+    SphereFilterRay fr;
+    if (CX::sphf && filter) fr.set(ray, cx.err_abs);
+    while (CX::sphf && groups) {
+        const uint32_t q0 = (uint32_t)__builtin_ctzll(groups) * psize, q1 = min(q0 + psize, pairs);
         groups &= groups - 1ull;
-        for (uint32_t i = i0; i < i1; ++i) {
-            float t;
-            const float4 r1 = ld(sph, 2 * i + 1);
-            if (sphere_t(ld(sph, 2 * i), r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
-                const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(r1.w)).w;
-                if (rng.next() > transparency) return true;
+        for (uint32_t q = q0; q < q1; ++q) {
+            bool keep_a = true, keep_b = true;
+            if (CX::sphf && filter) {
+                const v2f k = fr.pair(ld(frows, 4u * q), ld(frows, 4u * q + 1u), ld(frows, 4u * q + 2u), ld(frows, 4u * q + 3u));
+                keep_a = k.x >= 0.f; keep_b = k.y >= 0.f;
+            }
+#pragma unroll
+            for (uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t i = 2u * q + half;
+                if (!(half ? keep_b : keep_a) || i >= ns) continue;
+                float t;
+                const float4 r1 = ld(sph, 2 * i + 1);
+                if (sphere_t(ld(sph, 2 * i), r1, ray, t) && t < tmax && HRT_T_ACCEPT(t)) {
+                    const float transparency = ld(mats, HRT_MAT_ROWS * __float_as_uint(r1.w)).w;
+                    if (rng.next() > transparency) return true;
+                }
             }
         }
     }
@@ -1150,10 +1223,10 @@ __device__ __forceinline__ f3 direct_light(const CX &cx, const Surface &sf, cons
         color = color + ((mk(ld(L, 1)) * sf.albedo) * fmaxf(0.0f, dotLN)) * (float)(1. - (double)sf.transparency);  // lights[0] (N2)
         int blocked = 0;
         const float delta = l0.w / 2.f;
-        const uint32_t gsize = (cx.S->n_spheres + 63u) / 64u;
-        const uint64_t groups = (CX::exact || (cx.flags & HRT_FLAG_NO_SHADOW_CULL))
-                                    ? ~0ull  // every group: the reference's full loop (tests compare the two bit for bit)
-                                    : shadow_sphere_groups(cx.S, sf.p, lpos, fabsf(delta) * 1.0001f + 1e-6f, ray.time, gsize);
+        const bool cull = !(CX::exact || (cx.flags & HRT_FLAG_NO_SHADOW_CULL));
+        const uint64_t groups = !cull ? ~0ull  // every group, every sphere: the reference's full loop (tests compare the two bit for bit)
+                                      : (CX::sphf ? shadow_sphere_groups(cx.S, sf.p, lpos, fabsf(delta) * 1.0001f + 1e-6f, ray.time)
+                                                  : shadow_sphere_groups_scalar(cx.S, sf.p, lpos, fabsf(delta) * 1.0001f + 1e-6f, ray.time, (cx.S->n_spheres + 63u) / 64u));
         for (int j = 0; j < 10; ++j) {  // NB_ECH
             const f3 lp = lpos + rng.unit_vector() * delta;
             const f3 to = lp - sf.p;
@@ -1163,7 +1236,7 @@ __device__ __forceinline__ f3 direct_light(const CX &cx, const Surface &sf, cons
             sr.o = sf.p + Ls * HRT_EPS;
             sr.d = normalize(Ls);
             sr.time = ray.time;
-            if (shadow_blocked(cx, sr, tLight, rng, groups, gsize)) blocked++;
+            if (shadow_blocked(cx, sr, tLight, rng, groups, cull)) blocked++;
         }
         const float shadow = (float)(1. - (double)((float)blocked / 10.f));
         color = color * shadow;  // the running sum, earlier lights included (N3)

@@ -66,8 +66,14 @@
                            // an unfinished walk goes back to the T queue with its state
 #endif
 #ifndef HRT_SP_CYCLE_BOUND
-#define HRT_SP_CYCLE_BOUND (1u << 16)  // scheduler cycles one sample chunk of one work unit may take before the workgroup gives up
-#endif                                 // (a test build sets it to 3 to exercise the give-up path: Makefile, libhrt_var_bound.so)
+#define HRT_SP_CYCLE_BOUND (1u << 16)  // consecutive scheduler cycles (of either stream) that may run NOTHING -- no chunk, no new path, no
+#endif                                 // reduction -- before the workgroup gives up.  A cycle that runs any chunk is progress: every chunk
+                                       // consumes something finite (a path has <= 6 hit visits; a walk crosses <= HRT_WALK_CELLS cells of a
+                                       // tree hrt_scene_create has checked, and a leaf's cursor only advances), so the bound does not depend
+                                       // on how long a legal walk is -- a leaf of 65 534 triangles is ~5 500 T visits of one path, all progress
+#ifndef HRT_SP_GIVEUP_AFTER
+#define HRT_SP_GIVEUP_AFTER 0u         // test build only (Makefile, libhrt_var_bound.so: 3): give up after that many serial sections whatever
+#endif                                 // they ran, to exercise the path on which a launch reports HRT_ERR_DEVICE
 #ifndef HRT_SP_STREAMS
 #define HRT_SP_STREAMS 2   // independent path streams per workgroup (each with its own slots, queues and cycle counter).  With 2, a wave
 #endif                     // that runs out of chunks in one stream's cycle does not idle at a barrier: it arrives (an LDS counter) and goes
@@ -128,8 +134,9 @@ struct SpShared {        // what the streams of a workgroup share (8 dwords)
     uint32_t cur;            // the unit slot new paths come from
     uint32_t tiles_done;     // the rank's tile queue is exhausted
     uint32_t abort;          // a bound tripped: every wave leaves the scheduler, the workgroup leaves the kernel
-    uint32_t stall;          // serial sections since a unit was last opened or reduced (the bound of HRT_SP_CYCLE_BOUND)
-    uint32_t pad[3];
+    uint32_t stall;          // consecutive serial sections (either stream's) whose cycle had nothing to run (HRT_SP_CYCLE_BOUND)
+    uint32_t sections;       // serial sections so far (HRT_SP_GIVEUP_AFTER test builds)
+    uint32_t pad[2];
 };
 static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0 && sizeof(SpUnit) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
 static_assert(HRT_SP_STREAMS == 1 || HRT_SP_STREAMS == 2, "one or two streams");
@@ -236,7 +243,7 @@ __device__ __forceinline__ void sp_push_all(const SpLds &L, SpCtl &C, uint32_t o
     }
 }
 
-template <bool LIGHTS, bool EXACT = false>
+template <bool LIGHTS, bool EXACT = false, bool SPHF = false>
 __device__ __forceinline__ void stream_body(const DRender &R) {
     extern __shared__ uint4 s_raw[];
     SpLds L;
@@ -253,7 +260,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     uint32_t *tile_xy = reinterpret_cast<uint32_t *>(U + HRT_SP_UNITS);              // [unit slot][tile]: x0 | y0 << 16, ~0: no such tile
     float *s_lut = reinterpret_cast<float *>(tile_xy + HRT_SP_UNITS * HRT_SP_MAXG);  // the u8 -> float tables (512 floats)
     float4 *s_tabs = reinterpret_cast<float4 *>(s_lut + 512);            // 16-byte aligned: every size above is a multiple of 16
-    CtxT<EXACT, true> cx;
+    CtxT<EXACT, true, SPHF> cx;
     cx.S = (cscene)R.scene;
     const uint32_t tab_rows = cx.S->tab_rows;  // the scene's per-object tables: staged once, read per lane from LDS (CtxT)
     uint4 *s_units = reinterpret_cast<uint4 *>(s_tabs + tab_rows);
@@ -289,7 +296,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         C0.parity = 1; C0.done = 0; C0.arrive = 0; C0.ready = 0; C0.cursor = 0; C0.ngen = 0; C0.gen_n0 = 0; C0.gen_slot = 0; C0.gen_s0 = 0;
         C0.red_slot = HRT_SP_UNITS; C0.red_j = 0; C0.red_s0 = 0; C0.red_ns = 0; C0.more = 1;
         if (tid == 0) {
-            SH.lock = 0; SH.cur = 0; SH.tiles_done = 0; SH.abort = 0; SH.stall = 0;
+            SH.lock = 0; SH.cur = 0; SH.tiles_done = 0; SH.abort = 0; SH.stall = 0; SH.sections = 0;
             for (int k = 0; k < HRT_SP_UNITS; ++k) { U[k].state = SP_U_FREE; U[k].j = 0; U[k].s0 = 0; U[k].ns = 0; U[k].gen_next = 0; U[k].gen_total = 0; U[k].outstanding = 0; }
         }
     }
@@ -358,7 +365,6 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     break;
                 }
             }
-            bool progress = false;
             // 1. the reduction this stream ran in the cycle that has just ended is complete: the unit's next fold, or a free slot
             const uint32_t rs = C.red_slot;
             if (rs < HRT_SP_UNITS) {
@@ -369,7 +375,6 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 } else {
                     u.state = SP_U_FREE;
                 }
-                progress = true;
             }
             // 2. a unit whose every path has started and finished is reduced in the cycle now being prepared
             uint32_t red = HRT_SP_UNITS;
@@ -405,7 +410,6 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                                     tile_xy[k * HRT_SP_MAXG + t] = xy;
                                 }
                                 cur = k;
-                                progress = true;
                             }
                     if (cur < HRT_SP_UNITS) { U[cur].state = SP_U_GENERATING; SH.cur = cur; }
                 }
@@ -427,8 +431,14 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             C.ngen = ngen; C.gen_n0 = n0; C.gen_slot = gs; C.gen_s0 = U[gs].s0;
             C.more = generating ? 1u : 0u;
             C.done = idle ? 1u : 0u;  // (and nothing waiting in this stream: checked below)
-            if (progress) SH.stall = 0;
-            else if (++SH.stall > HRT_SP_CYCLE_BOUND) {  // bounded: a scheduling bug must not spin the GPU
+            // Bounded: a scheduling bug must not spin the GPU.  The cycle being prepared runs something when it has queue entries (the
+            // queue fills are final: every wave of the finished cycle has arrived), new paths or a reduction; only a run of cycles
+            // with NOTHING -- this stream waiting for the other one, or a unit state that can never advance -- counts.
+            uint32_t entries = ngen + (red < HRT_SP_UNITS ? 1u : 0u);  // what WILL run: whole chunks only while partial ones are deferred (below)
+            for (int q = 0; q < 5; ++q) entries += (HRT_SP_DEFER && generating) ? (C.cQ[q][par] & ~63u) : C.cQ[q][par];
+            const uint32_t stalled = entries != 0u ? (SH.stall = 0u) : ++SH.stall;
+            const uint32_t sections = ++SH.sections;
+            if (stalled > HRT_SP_CYCLE_BOUND || (HRT_SP_GIVEUP_AFTER != 0u && sections > HRT_SP_GIVEUP_AFTER)) {
                 // The frame is lost: flag it for the host (hrt_check_last_launch / hrt_render return HRT_ERR_DEVICE) and take
                 // the whole workgroup out of the kernel.  The other workgroups finish their tiles.
                 if (R.stamps) {
@@ -665,7 +675,8 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         const float v = ((float)py + rng.next()) / (float)R.h;
                         const float tm = rng.next();
                         ray = camera_ray<EXACT>(cam, u, v, tm);
-                        sp_st4(L, 5, slot, make_uint4(__float_as_uint(tm), rng.k0, rng.k1, n | (gs << 30)));
+                        pnum = n | (gs << 30);
+                        sp_st4(L, 5, slot, make_uint4(__float_as_uint(tm), rng.k0, rng.k1, pnum));
                         sp_st4(L, 6, slot, sp_pack(1.f, 1.f, 1.f, 0.f));                                  // throughput 1, radiance 0
                         sp_st4(L, 7, slot, make_uint4(0u, 0u, rng.i, 6u));                               // MAXBOUNCES
                         trace = true;
@@ -731,6 +742,21 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     SEG(4);  // spheres + squares
                     pmn = has_mesh ? mesh_gates(cx, ray) : 0u;
                     SEG(5);  // mesh gates
+                }
+                if (SPHF && trace && hn.kind == 0u && pmn == 0u) {
+                    // The builds for open scenes (a crowd of spheres under a sky): a ray that meets nothing ends its path HERE instead of
+                    // travelling to a miss chunk (Scene.h:302-303; one visit in four of random_spheres).  Throughput, radiance and the
+                    // bounces left were written to the record a moment ago by this lane (a new path: 1, 0, 6): read back, not kept live.
+                    f3 thr = mk(1.f, 1.f, 1.f);
+                    int remaining = 6;
+                    if (!is_gen) {
+                        const uint4 g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
+                        thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
+                        rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
+                        remaining = (int)g7.w;
+                    }
+                    rad = rad + thr * sky(cx, ray.d, remaining);
+                    trace = false; ended = true; last_seg = false;
                 }
                 if (last_seg) {  // HRT_SP_PRUNE bit 1: the closest hit of this ray is only asked whether it emits
                     bool dead;
@@ -820,6 +846,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 
 extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel(const DRender R) { hrtk::stream_body<false>(R); }
 extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_lights(const DRender R) { hrtk::stream_body<true>(R); }
+// scenes with a crowd of spheres (HRT_SPHERE_FILTER_MIN..128): the builds that carry the spheres' pair filter (hrt_kernels.hip CtxT)
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_sph(const DRender R) { hrtk::stream_body<false, false, true>(R); }
+extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_lights_sph(const DRender R) { hrtk::stream_body<true, false, true>(R); }
 // HRT_FLAG_EXACT_ONLY proof builds (no filters, no v_rcp_f32; CtxT in hrt_kernels.hip)
 extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_exact(const DRender R) { hrtk::stream_body<false, true>(R); }
 extern "C" __global__ void __launch_bounds__(HRT_SP_WG, HRT_SP_MINW) hrt_wgstream_kernel_lights_exact(const DRender R) { hrtk::stream_body<true, true>(R); }

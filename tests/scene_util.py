@@ -25,6 +25,29 @@ def many_squares(gpu, n_quads, n_meshes):
     return s
 
 
+def many_spheres(gpu, n, n_lights, dark=False):
+    """A crowd of n spheres over a floor (mirror / glass / diffuse, some moving, some tiny, some overlapping, one enclosing the
+    camera's side of the scene partly), n_lights point lights: exercises the packed pair filter of the closest-hit loop and of
+    the shadow rays on both sides of its limits (8 <= n <= 128), odd counts (the last sphere pairs with itself) and far / near /
+    tangent geometry."""
+    M = gpu.Material.make
+    rng = np.random.default_rng(7000 + 13 * n + n_lights)
+    s = gpu.HostScene()
+    s.set_sky(dark)
+    for i in range(n_lights):
+        s.add_light((float(rng.uniform(-4, 4)), float(rng.uniform(4, 9)), float(rng.uniform(-6, 3))), float(rng.uniform(0.5, 2.0)))
+    s.add_quad((-40, -2, -60), (1, 0, 0), (0, 0, 1), 80, 70, M(albedo=(0.7, 0.7, 0.7)))
+    for i in range(n):
+        kind = i % 4
+        r = float(rng.choice([0.05, 0.3, 0.8, 1.5, 4.0], p=[0.1, 0.3, 0.3, 0.25, 0.05]))
+        c = (float(rng.uniform(-12, 12)), float(-2 + r * rng.uniform(0.6, 1.4)), float(rng.uniform(-40, 1)))
+        mat = M(albedo=tuple(rng.uniform(0.2, 1, 3)), type=gpu.MAT_GLASS if kind == 0 else (gpu.MAT_MIRROR if kind == 1 else gpu.MAT_DIFFUSE),
+                transparency=0.6 if kind == 0 else (0.3 if kind == 3 else 0.0), index_medium=1.5,
+                motion=(0.0, float(rng.uniform(0, 0.8)), 0.0) if i % 3 == 0 else (0, 0, 0))
+        s.add_sphere(c, r, mat)
+    return s
+
+
 def describe_difference(a, b):
     """Text for an assertion message: how many pixels differ and by how much."""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))

@@ -13,7 +13,7 @@ bit-identical: one false negative of a filter anywhere in ~10^8 paths x 6 bounce
 import numpy as np
 import pytest
 
-from scene_util import describe_difference, many_squares
+from scene_util import describe_difference, many_spheres, many_squares
 
 pytestmark = pytest.mark.gpu
 
@@ -22,6 +22,9 @@ def _scene(gpu, name, aspect):
     if name.startswith("many_squares"):
         _, nq, nm = name.split(":")
         host = many_squares(gpu, int(nq), int(nm))
+    elif name.startswith("many_spheres"):
+        _, n, nl = name.split(":")
+        host = many_spheres(gpu, int(n), int(nl))
     else:
         host = gpu.HostScene().setup(name, aspect, 1)
     desc = host.flatten()
@@ -31,6 +34,10 @@ def _scene(gpu, name, aspect):
 FULL = [("cornell_box", 1920, 1080, 8), ("cornell_mesh", 1920, 1080, 8), ("random_spheres", 1920, 1080, 8),
         ("mesh_in_box", 1920, 1080, 8), ("backrooms_pool", 1920, 1080, 8), ("flamingo", 1920, 1080, 8),
         ("many_squares:33:0", 1920, 1080, 8), ("many_squares:64:2", 1920, 1080, 8), ("many_squares:70:5", 1920, 1080, 8),
+        # crowds of spheres: the packed pair filter of the closest-hit loop and of the shadow rays (kernel builds `_sph`, 8..128
+        # spheres), below, inside and beyond its range, odd counts, 0 / 1 / 2 lights
+        ("many_spheres:8:1", 1920, 1080, 4), ("many_spheres:33:0", 1920, 1080, 4), ("many_spheres:65:2", 1280, 720, 4),
+        ("many_spheres:128:1", 1280, 720, 4), ("many_spheres:131:1", 960, 540, 2), ("many_spheres:7:1", 960, 540, 4),
         # the meshes with the most irregular triangles (the proof build tests every one of them and asks every reference box)
         ("raccoon", 1920, 1080, 4), ("flamingo_pond", 1920, 1080, 4)]
 

@@ -142,8 +142,8 @@ def test_raytracer_driver_writes_the_file_the_library_renders(gpu, tmp_path):
 
 
 def test_a_launch_that_gives_up_is_reported_not_returned(gpu, tmp_path):
-    """The streaming kernel's scheduler has a cycle bound so that a bug can never spin the GPU.  libhrt_var_bound.so is the
-    same library built with the bound at 3 cycles (Makefile): every entry point that hands back pixels must then fail
+    """The streaming kernel's scheduler has a bound on the cycles it may spin with nothing to run, so that a bug can never spin
+    the GPU.  libhrt_var_bound.so is the same library built to give up after 3 serial sections (Makefile): every entry point that hands back pixels must then fail
     with HRT_ERR_DEVICE -- hrt_render (with and without stats), hrt_check_last_launch after the asynchronous entry points,
     hrt_last_kernel_ms -- and the process must stay usable (the lane-per-pixel kernel has no such bound and still renders)."""
     import subprocess, sys, textwrap
@@ -188,6 +188,9 @@ def test_render_multi_gives_the_bits_of_render(gpu, name, w, h, spp):
     want_g, _ = dev.render(cam, w, h, spp, seed=9, flags=gpu.FLAG_GAMMA)
     for slots in ([0], [0, 0], [0, 0, 0], [0] * 5):
         ms = gpu.MultiScene(desc, slots)
+        # one slot = distinct ordinals: the gather of one rank goes through an RCCL communicator (ncclCommInitAll + ncclGather);
+        # a repeated ordinal cannot (a communicator does not take a device twice): peer copies
+        assert ms.gather == ("rccl" if len(slots) == 1 else "peer"), (slots, ms.gather, ms.note)
         got, st = ms.render(cam, w, h, spp, seed=9)
         assert np.array_equal(got, want), f"{len(slots)} slots"
         assert st.samples == w * h * spp and st.kernel_ms > 0
@@ -202,6 +205,37 @@ def test_render_multi_gives_the_bits_of_render(gpu, name, w, h, spp):
         gpu.MultiScene(desc, [0, 99])          # no such device
     img, _ = dev.render(cam, w, h, spp, seed=9)  # the single-GPU scene still works afterwards
     assert np.array_equal(img, want)
+
+
+def test_multi_gather_can_be_chosen_and_is_reported(gpu, monkeypatch, tmp_path):
+    """HRT_MULTI_GATHER=peer forces the peer copies even where a communicator exists; =rccl refuses a repeated ordinal instead
+    of falling back; the driver prints which gather ran.  Both forms give hrt_render's bits."""
+    import subprocess
+    w, h, spp = 96, 54, 2
+    desc, dev, cam = build(gpu, "cornell_mesh", w / h)
+    want, _ = dev.render(cam, w, h, spp, seed=3)
+    monkeypatch.setenv("HRT_MULTI_GATHER", "peer")
+    ms = gpu.MultiScene(desc, [0])
+    assert ms.gather == "peer" and np.array_equal(ms.render(cam, w, h, spp, seed=3)[0], want)
+    ms.close()
+    monkeypatch.setenv("HRT_MULTI_GATHER", "rccl")
+    ms = gpu.MultiScene(desc, [0])
+    assert ms.gather == "rccl" and ms.note == ""
+    assert np.array_equal(ms.render(cam, w, h, spp, seed=3)[0], want)
+    assert np.array_equal(ms.render(cam, 2 * w, 2 * h, 1, seed=3)[0], dev.render(cam, 2 * w, 2 * h, 1, seed=3)[0])  # buffers regrown
+    ms.close()
+    with pytest.raises(gpu.HrtError, match="distinct"):
+        gpu.MultiScene(desc, [0, 0])
+    monkeypatch.setenv("HRT_MULTI_GATHER", "carrier pigeon")
+    with pytest.raises(gpu.HrtError, match="rccl or peer"):
+        gpu.MultiScene(desc, [0])
+    monkeypatch.delenv("HRT_MULTI_GATHER")
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hai719-raytracing_amd")
+    for extra, name in ((["--gpus", "1"], "rccl"), (["--devices", "0,0"], "peer")):
+        r = subprocess.run([os.path.join(pkg, "raytracer"), "--scene", "cornell_box", "--w", "32", "--h", "32", "--spp", "1", "--assets",
+                            os.path.join(os.path.dirname(pkg), "assets"), "--out", os.path.join(str(tmp_path), "g.ppm")] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and f"gather: {name}" in r.stdout, r.stdout + r.stderr
 
 
 def test_raytracer_driver_renders_across_slots(gpu, tmp_path):
