@@ -300,6 +300,101 @@ __device__ __forceinline__ bool walk_some_per_lane(const CX &cx, const Ray &ray,
     return parked == 0u;
 }
 
+// The T visit of the streaming kernel: the same walks, the same transitions of their state (mesh_walk_start, kd_descend, the
+// leaf's triangles in batches of HRT_LEAF_BATCH, the exit face and its rope, the merge of a finished mesh in mesh order), but
+// SCHEDULED BY VOTE.  A trip of kd_trip runs descent, leaf fetch, triangle batch and exit one after the other, each under the
+// mask of the lanes that happen to need it: with 64 walks in different places the triangle batch -- half of a trip's
+// instructions -- ran with 14-17 of 64 lanes (rocprofv3 on the pool scene: 0.83 of the SIMD cycles issue vector instructions at
+// 0.59 lane utilisation: the walk is bound by instruction issue, not by memory).  Here every lane is in one of three states and
+// each step executes the ONE block most lanes wait for:
+//     S  no walk in progress: start the lane's next mesh (irregular triangles, root clip)
+//     B  inside a leaf with triangles left: test the next HRT_LEAF_BATCH of them
+//     M  anything else: leave a finished leaf through its exit face (or end the walk there), descend one treelet, fetch the
+//        leaf the lane has arrived at
+// so a block runs with at least a third -- in practice most -- of the lanes that still walk.  Which lane advances when cannot
+// change a result: a walk depends on its ray and its mesh only.  `steps` blocks per visit; an unfinished walk keeps the same
+// seven dwords of state as before (a lane inside a leaf re-fetches it at the next visit).
+template <class CX>
+__device__ __forceinline__ bool walk_vote(const CX &cx, const Ray &ray, uint32_t &parked, Walk &w, Hit &h, int steps) {
+    if (CX::exact && (cx.flags & HRT_FLAG_MESH_BRUTE)) return walk_some(cx, ray, parked, w, h, steps);
+    const f3 inv = ray_inv<CX::exact>(ray);
+    const typename CX::tabmesh meshes = cx.tmesh;
+    gu4 g_units = (gu4)cx.S->kd_units;
+    const Soup sp = soup_of(cx.S);
+    WalkCursor c;
+    c.open(w, ray);
+    bool in_leaf = false;  // the four units of the leaf c.ref names are in l0, l1, rp0, rp1
+    uint4 l0 = make_uint4(0u, 0u, 0u, 0u), l1 = l0, rp0 = l0, rp1 = l0;
+    uint32_t first = 0u, cnt = 0u;
+    uint32_t tri_base = parked ? (meshes + (uint32_t)__builtin_ctz(parked))->tri_base : 0u;
+    auto finish_mesh = [&]() {  // the walk of the lane's current mesh is complete: Scene.h:222-228's `t >= EPSILON && t < best`
+        const float t = w.best_t;
+        if (t < HRT_FLT_MAX && t < h.t && HRT_T_ACCEPT(t)) {
+            h.kind = 3; h.index = (uint32_t)__builtin_ctz(parked); h.t = t; h.tri = w.best_tri; h.a0 = w.bu; h.a1 = w.bv;
+        }
+        parked &= parked - 1u;
+        c.ref = HRT_KD_NIL;
+        in_leaf = false;
+    };
+    for (int step = 0; step < steps; ++step) {
+        const bool alive = parked != 0u;
+        const bool want_s = alive && c.ref == HRT_KD_NIL;
+        const bool want_b = alive && !want_s && in_leaf && c.k < cnt;
+        const bool want_m = alive && !want_s && !want_b;
+        const uint32_t n_s = (uint32_t)__popcll(__ballot(want_s)), n_b = (uint32_t)__popcll(__ballot(want_b)), n_m = (uint32_t)__popcll(__ballot(want_m));
+        if ((n_s | n_b | n_m) == 0u) break;
+        if (n_b >= n_m && n_b >= n_s) {
+            if (want_b) {
+                bool found_ = false;
+                c.k = tri_test_run(sp, first, cnt, c.k, ray, w.best_t, w.best_tri, w.bu, w.bv, found_);
+            }
+        } else if (n_m >= n_s) {
+            if (want_m) {
+                if (in_leaf) {  // every triangle of the leaf has been tested: leave the cell through its exit face (kd_trip)
+                    const float ex = ((ray.d.x > 0.f ? __uint_as_float(l1.x) : __uint_as_float(l0.x)) - ray.o.x) * inv.x;
+                    const float ey = ((ray.d.y > 0.f ? __uint_as_float(l1.y) : __uint_as_float(l0.y)) - ray.o.y) * inv.y;
+                    const float ez = ((ray.d.z > 0.f ? __uint_as_float(l1.z) : __uint_as_float(l0.z)) - ray.o.z) * inv.z;
+                    float t_exit = HRT_FLT_MAX;
+                    uint32_t face = 6;
+                    if (ray.d.x != 0.f && ex < t_exit) { t_exit = ex; face = ray.d.x > 0.f ? 1u : 0u; }
+                    if (ray.d.y != 0.f && ey < t_exit) { t_exit = ey; face = ray.d.y > 0.f ? 3u : 2u; }
+                    if (ray.d.z != 0.f && ez < t_exit) { t_exit = ez; face = ray.d.z > 0.f ? 5u : 4u; }
+                    in_leaf = false;
+                    if (w.best_t <= t_exit || face == 6) {
+                        finish_mesh();  // the closest hit lies inside the cells already visited
+                    } else {
+                        c.t_entry = fmaxf(c.t_entry, t_exit);
+                        c.p = ray.o + c.t_entry * ray.d;
+                        const uint4 rp = (face >> 2) ? rp1 : rp0;
+                        const uint32_t sel = face & 3u;
+                        c.ref = sel == 0 ? rp.x : (sel == 1 ? rp.y : (sel == 2 ? rp.z : rp.w));
+                        c.k = 0xFFFFu;
+                        if (++c.count >= HRT_WALK_CELLS) c.ref = HRT_KD_NIL;  // mesh_traverse's bound on the cells of one walk
+                        if (c.ref == HRT_KD_NIL) finish_mesh();              // left the tree (or hit the bound): complete
+                    }
+                }
+                const bool moving = parked != 0u && c.ref != HRT_KD_NIL;  // (a lane whose mesh has just ended starts its next one in an S step)
+                if (moving && !(c.ref & HRT_KD_LEAF)) c.ref = kd_descend(g_units, cx, c.ref, c.p, ray.d);  // two levels
+                if (moving && (c.ref & HRT_KD_LEAF)) {
+                    kd_fetch4(g_units, cx, c.ref & ~HRT_KD_LEAF, l0, l1, rp0, rp1);
+                    first = tri_base + l0.w; cnt = l1.w;
+                    if (c.k == 0xFFFFu) c.k = 0;
+                    in_leaf = true;
+                }
+            }
+        } else {
+            if (want_s) {
+                const typename CX::tabmesh M = meshes + (uint32_t)__builtin_ctz(parked);
+                tri_base = M->tri_base;
+                if (mesh_walk_start(cx, M, ray, inv, w)) { c.open(w, ray); in_leaf = false; }
+                else finish_mesh();
+            }
+        }
+    }
+    c.close(w);
+    return parked == 0u;
+}
+
 // One stage B visit for a parked stream.
 template <class CX>
 __device__ __forceinline__ void walk_visit(const CX &cx, PathState &p) {

@@ -1306,6 +1306,9 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
 #endif
     __syncthreads();
     const bool has_mesh = cx.S->n_meshes != 0u;
+    // exact path pruning, as in the streaming kernel (hrt_stream.hip HRT_SP_PRUNE; never in the proof builds)
+    const bool prune = !EXACT && cx.S->prune_ok != 0u;
+    const bool sky_is_zero = cx.S->skybox_image < 0 && cx.S->dark_sky != 0;
 
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
@@ -1359,12 +1362,23 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                 parked &= 0x80000000u;
 #endif
                 stage = parked ? 1u : 2u;
+                if (!LIGHTS && prune && remaining == 1) {  // the path's last segment: only an emitting closest hit can still reach the sample
+                    bool dead;
+                    if (h.kind == 0u) {
+                        dead = sky_is_zero;
+                    } else {
+                        const uint32_t mat = h.kind == 1u ? __float_as_uint(ld(cx.ts, HRT_SPHERE_ROWS * h.index + 1u).w)
+                                                          : __float_as_uint(ld(cx.tq, HRT_QUAD_ROWS * h.index + 4u).w);
+                        dead = __float_as_uint(ld(cx.tm, HRT_MAT_ROWS * mat + 1u).w) == 0u;
+                    }
+                    if (dead) { h.kind = 0u; parked = 0u; stage = 3u; }  // ends below with the radiance it has
+                }
             }
             STAMP(4);
             // ---- stage B: walk the meshes for the parked lanes once enough of them have gathered
             if (has_mesh) {
                 const uint64_t waiting = __ballot(live && stage == 1u);
-                const uint64_t ready = __ballot(live && stage == 2u);
+                const uint64_t ready = __ballot(live && stage >= 2u);
                 if (waiting != 0ull && (__popcll(waiting) >= HRT_MESH_BATCH || ready == 0ull)) {
                     if (live && stage == 1u) {
                         meshes_hit(cx, ray, parked, h);
@@ -1374,9 +1388,11 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
             }
             STAMP(5);
             // ---- stage C: shade, scatter, end of path
-            if (live && stage == 2u) {
+            if (live && stage >= 2u) {
                 bool ended;
-                if (h.kind == 0u) {
+                if (stage == 3u) {
+                    ended = true;  // pruned on its last segment (stage A): nothing is added
+                } else if (h.kind == 0u) {
                     rad = rad + thr * sky(cx, ray.d, remaining);
                     ended = true;
                 } else {
@@ -1390,7 +1406,7 @@ __device__ __forceinline__ void trace_body(const DRender &R) {
                     scatter(sf, ray, rng);
                     STAMP(8);
                     --remaining;
-                    ended = (remaining == 0);
+                    ended = (remaining == 0) || (prune && thr.x == 0.f && thr.y == 0.f && thr.z == 0.f);
                 }
                 if (ended) {
                     sum = sum + mk(rad.x / 6.f, rad.y / 6.f, rad.z / 6.f);  // Scene.h:348

@@ -65,6 +65,12 @@
 #define HRT_SP_TRIPS 6     // KD-walk trips per T visit (A/B 1080p@256, ms Cornell+mesh / mesh_in_box / pool: 6 -> 264 / 301 / 649, 8 -> 264 / 305 / 659, 12 -> 265 / 311 / 686);
                            // an unfinished walk goes back to the T queue with its state
 #endif
+#ifndef HRT_SP_VOTE
+#define HRT_SP_VOTE 0      // 1: T visits schedule the blocks of the walk by vote (hrt_dual.hip walk_vote); 0: HRT_SP_TRIPS trips of kd_trip
+#endif
+#ifndef HRT_SP_STEPS
+#define HRT_SP_STEPS 16    // blocks per T visit of walk_vote
+#endif
 #ifndef HRT_SP_CYCLE_BOUND
 #define HRT_SP_CYCLE_BOUND (1u << 16)  // consecutive scheduler cycles (of either stream) that may run NOTHING -- no chunk, no new path, no
 #endif                                 // reduction -- before the workgroup gives up.  A cycle that runs any chunk is progress: every chunk
@@ -621,7 +627,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #endif
                 SEG(0);  // T: record loaded
                 if (act) {
+#if HRT_SP_VOTE
+                    walked = walk_vote(cx, ray, pm, w, h, HRT_SP_STEPS);
+#else
                     walked = multi_mesh ? walk_some_per_lane(cx, ray, pm, w, h, HRT_SP_TRIPS) : walk_some(cx, ray, pm, w, h, HRT_SP_TRIPS);
+#endif
                 }
                 SEG(1);  // T: walk
                 if (act) {
