@@ -13,9 +13,11 @@
 // PIN STATUS (see DESIGN.md "Oracle"):
 //   pinned against the reference's own code compiled from /root/reference
 //   (oracle/ref_parts.cpp -> oracle/_ref/): Triangle.h, AABB.h, Functions.cpp,
-//   Vec3.h, Ray.h/Line.h, imageLoader.cpp  (rows a3, a11, a12, a16, a17, a18).
+//   Vec3.h, Ray.h/Line.h, imageLoader.cpp and matrixUtilities.h (gluInvertMatrix +
+//   screen_space_to_world_space_ray: camera rays bit for bit on 16 poses x 1024
+//   (u, v))  (rows a2, a3, a11, a12, a16, a17, a18).
 //   PARITY UNPINNED for Sphere.h, Square.h, Material.cpp, KDTree.cpp, Mesh.cpp,
-//   Scene.h and main.cpp (rows a1, a2, a4-a10, a13-a15): those translation
+//   Scene.h and main.cpp (rows a1, a4-a10, a13-a15): those translation
 //   units include <GL/glut.h>, which this image lacks, the reference ships no
 //   tests or golden vectors, and stand-in headers are not allowed; they are
 //   restated from the source text only.

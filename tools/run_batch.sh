@@ -1,5 +1,3 @@
 # scratch batch for one gpurun call (edited per experiment)
-timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests.log 2>&1; tail -4 gpurun_out/gpu_tests.log
-python tools/make_frame_means.py > gpurun_out/frame_means.log 2>&1; tail -8 gpurun_out/frame_means.log
-HRT_SPP=64 python tools/time_only.py cornell_box cornell_mesh 2>&1 | grep Msamples
-HRT_KERNEL=single HRT_SPP=64 python tools/time_only.py cornell_box 2>&1 | grep Msamples
+HRT_SPP=64 bash tools/variants.sh run cornell_mesh mesh_in_box backrooms_pool > gpurun_out/a8_var.log 2>&1; grep -E "Msamples|FAILED" gpurun_out/a8_var.log
+for leaf in 2 3 6 8; do HRT_KD_LEAF=$leaf HRT_SPP=64 python tools/time_only.py cornell_mesh mesh_in_box backrooms_pool 2>&1 | grep Msamples; done
