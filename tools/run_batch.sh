@@ -1,3 +1,5 @@
-# scratch batch for one gpurun call (edited per experiment)
-HRT_SPP=64 bash tools/variants.sh run cornell_mesh mesh_in_box backrooms_pool > gpurun_out/a8_var.log 2>&1; grep -E "Msamples|FAILED" gpurun_out/a8_var.log
-for leaf in 2 3 6 8; do HRT_KD_LEAF=$leaf HRT_SPP=64 python tools/time_only.py cornell_mesh mesh_in_box backrooms_pool 2>&1 | grep Msamples; done
+# batch for one gpurun call: the GPU suite, smoke, the profiles of every configuration, the default bench
+timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests.log 2>&1; tail -4 gpurun_out/gpu_tests.log
+python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log
+bash tools/profile.sh r03 > gpurun_out/profile_r03.log 2>&1; grep -E "^cfg|failed|==" gpurun_out/profile_r03.log
+python bench.py > gpurun_out/bench_r03b.log 2>&1; tail -c 5000 gpurun_out/bench_r03b.log
