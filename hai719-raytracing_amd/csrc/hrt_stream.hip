@@ -65,6 +65,10 @@
 #define HRT_SP_TRIPS 6     // KD-walk trips per T visit (A/B 1080p@256, ms Cornell+mesh / mesh_in_box / pool: 6 -> 264 / 301 / 649, 8 -> 264 / 305 / 659, 12 -> 265 / 311 / 686);
                            // an unfinished walk goes back to the T queue with its state
 #endif
+#ifndef HRT_SP_TPRIO
+#define HRT_SP_TPRIO 3     // s_setprio level of a wave while it runs a T chunk (0: none).  1080p@64, ms Cornell+mesh / mesh_in_box / pool:
+                           // 0 -> 40.92 / 47.19 / 75.39, 1 -> 40.79 / 46.38 / 74.76, 3 -> 40.76 / 46.38 / 74.28
+#endif
 #ifndef HRT_SP_VOTE
 #define HRT_SP_VOTE 0      // 1: T visits schedule the blocks of the walk by vote (hrt_dual.hip walk_vote); 0: HRT_SP_TRIPS trips of kd_trip
 #endif
@@ -598,6 +602,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #endif
             if (c < nT) {
                 // ---------------- T: mesh walk
+#if HRT_SP_TPRIO
+                __builtin_amdgcn_s_setprio(HRT_SP_TPRIO);  // a walk is a chain of dependent loads with a few instructions between them: let them issue first
+#endif
                 const uint32_t e = HRT_SP_THALF ? c * 32u + lane : c * 64u + lane;
                 const bool act = e < cTin && (!HRT_SP_THALF || lane < 32u);
                 uint32_t slot = 0, kind = 0, pm = 0, ref_in = HRT_KD_NIL, pm_before = 0;
@@ -648,6 +655,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     }
                     kind = h.kind;
                 }
+#if HRT_SP_TPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 // unfinished: joins the next cycle's T chunks; finished: the closest-hit queue of its kind
                 sp_push_all(L, C, parity ^ 1u, !act ? SP_TO_NONE : (walked ? 1u + kind : 0u), slot);
                 SEG(2);  // T: stores + appends
