@@ -267,7 +267,11 @@ FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t
     }
 
     const auto t_start = std::chrono::steady_clock::now();
-    Builder b(params, nt);
+    KDBuildParams tuned = params;  // (A/B sweeps of the heuristic's constants on the GPU box: tools/time_only.py)
+    if (const char *e = std::getenv("HRT_KD_CT")) tuned.cost_traverse = (float)atof(e);
+    if (const char *e = std::getenv("HRT_KD_CI")) tuned.cost_intersect = (float)atof(e);
+    if (const char *e = std::getenv("HRT_KD_EB")) tuned.empty_bonus = (float)atof(e);
+    Builder b(tuned, nt);
     unsigned threads = params.threads ? params.threads : std::thread::hardware_concurrency();
     if (const char *e = std::getenv("HRT_KD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
     threads = std::min(threads, 16u);  // measured on the MI355X host (pool flamingo, 31 575 triangles): 1 -> 273 ms, 4 -> 177, 16 -> 112, 64 -> 173
