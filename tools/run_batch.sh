@@ -1,1 +1,4 @@
-HRT_SPP=64 bash tools/variants.sh run cornell_mesh backrooms_pool random_spheres flamingo > gpurun_out/a11_var.log 2>&1; grep -E "Msamples|FAILED" gpurun_out/a11_var.log | sed 's/lds=32 leaf=4//; s/1920x1080@64: min//; s/med.*-> */ /; s/vgpr.*//'
+# batch for one gpurun call: the GPU suite, smoke, the profiles of every configuration, the default bench
+timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests.log 2>&1; tail -4 gpurun_out/gpu_tests.log
+python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
+bash tools/profile.sh r03 > gpurun_out/profile_r03.log 2>&1; grep -E "^cfg|failed|==" gpurun_out/profile_r03.log | cut -c1-400
