@@ -124,6 +124,7 @@ def host_lib() -> C.CDLL:
         lib.hrt_host_scene_add_light.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
         lib.hrt_host_scene_set_sky.argtypes = [C.c_void_p, C.c_int32]
         lib.hrt_host_scene_set_kd_params.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.hrt_host_scene_set_kd_builder.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.hrt_host_scene_flatten.argtypes = [C.c_void_p, C.c_void_p]
         lib.hrt_host_scene_kd_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.hrt_host_scene_irregular_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -258,6 +259,17 @@ class HostScene:
 
     def set_kd_params(self, leaf_max: int = 0, max_depth: int = 0):
         self._check(self._lib.hrt_host_scene_set_kd_params(self._h, leaf_max, max_depth))
+
+    def set_kd_builder(self, fn=None, user=None):
+        """hrt_host_scene_set_kd_builder: ``fn`` a hrt_kd_builder_fn (a ctypes function pointer, or an address), None = the
+        host's own threaded builder.  ``set_kd_builder("gpu")`` selects libhrt.so's hrt_kd_build_gpu (needs ``init``)."""
+        if fn == "gpu":
+            fn = C.cast(device_lib().hrt_kd_build_gpu, C.c_void_p)
+        elif fn is not None and not isinstance(fn, (int, C.c_void_p)):
+            self._kd_builder_keepalive = fn  # the ctypes callback object must outlive the flatten
+            fn = C.cast(fn, C.c_void_p)
+        self._check(self._lib.hrt_host_scene_set_kd_builder(self._h, fn, user))
+        return self
 
     def flatten(self) -> C.c_void_p:
         """Builds the KD-trees; returns ``const hrt_scene_desc*`` (valid until the next flatten / close)."""

@@ -258,6 +258,8 @@ struct hrt_scene {
     int device = 0;                     // the device that holds this scene (current when it was created)
 };
 
+#include "hrt_kdbuild.hip"
+
 extern "C" {
 
 const char *hrt_last_error(void) { return g_error.c_str(); }
@@ -1386,5 +1388,21 @@ int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h) {
 }
 
 #include "hrt_multi.hip"
+
+int hrt_kd_build_gpu(const hrt_kd_build_input *in, hrt_kd_build_output *out, void *user) {
+    (void)user;
+    if (!in || !out || (in->n_refs && (!in->ids || !in->lo || !in->hi))) return fail(HRT_ERR_INVALID, "hrt_kd_build_gpu: bad argument");
+    if (!g_rt.ready) return fail(HRT_ERR_STATE, "hrt_kd_build_gpu: call hrt_init first");
+    std::memset(out, 0, sizeof(*out));
+    {
+        const int drc = use_device(g_rt.device);
+        if (drc != HRT_OK) return drc;
+    }
+    try {
+        return kd_build_gpu_impl(in, out);
+    } catch (const std::exception &e) {
+        return fail(HRT_ERR_STATE, std::string("hrt_kd_build_gpu: ") + e.what());
+    }
+}
 
 }  // extern "C"

@@ -220,6 +220,13 @@ int hrt_host_scene_set_kd_params(hrt_host_scene *s, uint32_t leaf_max, uint32_t 
     return HRT_OK;
 }
 
+int hrt_host_scene_set_kd_builder(hrt_host_scene *s, hrt_kd_builder_fn fn, void *user) {
+    if (!s) return fail(HRT_ERR_INVALID, "NULL scene");
+    s->scene.kd_params.builder = fn;
+    s->scene.kd_params.builder_user = user;
+    return HRT_OK;
+}
+
 int hrt_host_scene_flatten(hrt_host_scene *s, const hrt_scene_desc **out) {
     if (!s || !out) return fail(HRT_ERR_INVALID, "flatten: NULL argument");
     try {

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <thread>
 #include <deque>
 
@@ -229,68 +230,9 @@ struct Builder {
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
-}  // namespace
-
-FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t *indices,
-                             uint32_t nt, const KDBuildParams &params, const uint8_t *skip) {
+// Ropes and the flattened unit array of a built tree (nodes in b.nodes, whoever built them).
+FlatKDTree finish_flat_kdtree(Builder &b, int root_node, const Box &root, uint32_t nt, std::chrono::steady_clock::time_point t_start, unsigned threads = 0) {
     FlatKDTree out;
-    (void)nv;
-    std::vector<TriRef> refs;
-    refs.reserve(nt);
-    Box root;
-    for (int a = 0; a < 3; ++a) { root.lo[a] = INFINITY; root.hi[a] = -INFINITY; }
-    for (uint32_t t = 0; t < nt; ++t) {
-        if (skip && skip[t]) continue;
-        refs.emplace_back();
-        TriRef &r = refs.back();
-        r.id = t;
-        for (int a = 0; a < 3; ++a) { r.b.lo[a] = INFINITY; r.b.hi[a] = -INFINITY; }
-        for (int k = 0; k < 3; ++k) {
-            const float *p = positions + 3 * (size_t)indices[3 * (size_t)t + k];
-            for (int a = 0; a < 3; ++a) {
-                r.b.lo[a] = std::min(r.b.lo[a], p[a]);
-                r.b.hi[a] = std::max(r.b.hi[a], p[a]);
-            }
-        }
-        for (int a = 0; a < 3; ++a) {
-            root.lo[a] = std::min(root.lo[a], r.b.lo[a]);
-            root.hi[a] = std::max(root.hi[a], r.b.hi[a]);
-        }
-    }
-    if (refs.empty()) return out;  // no (regular) triangle: no tree
-    nt = (uint32_t)refs.size();
-    // Pad the root cell so that hits on the hull are strictly inside it.
-    for (int a = 0; a < 3; ++a) {
-        float pad = 1e-4f * std::max(1.f, std::max(std::fabs(root.lo[a]), std::fabs(root.hi[a])));
-        root.lo[a] -= pad;
-        root.hi[a] += pad;
-    }
-
-    const auto t_start = std::chrono::steady_clock::now();
-    KDBuildParams tuned = params;  // (A/B sweeps of the heuristic's constants on the GPU box: tools/time_only.py)
-    if (const char *e = std::getenv("HRT_KD_CT")) tuned.cost_traverse = (float)atof(e);
-    if (const char *e = std::getenv("HRT_KD_CI")) tuned.cost_intersect = (float)atof(e);
-    if (const char *e = std::getenv("HRT_KD_EB")) tuned.empty_bonus = (float)atof(e);
-    Builder b(tuned, nt);
-    unsigned threads = params.threads ? params.threads : std::thread::hardware_concurrency();
-    if (const char *e = std::getenv("HRT_KD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
-    threads = std::min(threads, 16u);  // measured on the MI355X host (pool flamingo, 31 575 triangles): 1 -> 273 ms, 4 -> 177, 16 -> 112, 64 -> 173
-    int root_node;
-    if (threads > 1 && nt > 4096) {
-        std::vector<Builder::Task> tasks;
-        b.tasks = &tasks;
-        b.spawn_below = std::max<size_t>(512, nt / (4u * threads));  // SAH first cuts empty space: split by size, not by depth
-        root_node = b.build(root, refs, 0);  // the root itself (depth 0) is never a task
-        b.tasks = nullptr;
-        const auto t_top = std::chrono::steady_clock::now();
-        b.run_tasks(tasks, threads);
-        b.splice(tasks);
-        if (std::getenv("HRT_KD_VERBOSE"))
-            std::fprintf(stderr, "kd build: top %.1f ms, %zu subtree tasks\n",
-                         std::chrono::duration<double, std::milli>(t_top - t_start).count(), tasks.size());
-    } else {
-        root_node = b.build(root, refs, 0);
-    }
     const auto t_built = std::chrono::steady_clock::now();
     const int nil[6] = {-1, -1, -1, -1, -1, -1};
     b.assign_ropes(root_node, nil);
@@ -361,6 +303,110 @@ FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t
                      ms(t_start, t_built), ms(t_built, t_roped), ms(t_roped, std::chrono::steady_clock::now()));
     }
     return out;
+}
+
+}  // namespace
+
+FlatKDTree build_flat_kdtree(const float *positions, uint32_t nv, const uint32_t *indices,
+                             uint32_t nt, const KDBuildParams &params, const uint8_t *skip) {
+    FlatKDTree out;
+    (void)nv;
+    std::vector<TriRef> refs;
+    refs.reserve(nt);
+    Box root;
+    for (int a = 0; a < 3; ++a) { root.lo[a] = INFINITY; root.hi[a] = -INFINITY; }
+    for (uint32_t t = 0; t < nt; ++t) {
+        if (skip && skip[t]) continue;
+        refs.emplace_back();
+        TriRef &r = refs.back();
+        r.id = t;
+        for (int a = 0; a < 3; ++a) { r.b.lo[a] = INFINITY; r.b.hi[a] = -INFINITY; }
+        for (int k = 0; k < 3; ++k) {
+            const float *p = positions + 3 * (size_t)indices[3 * (size_t)t + k];
+            for (int a = 0; a < 3; ++a) {
+                r.b.lo[a] = std::min(r.b.lo[a], p[a]);
+                r.b.hi[a] = std::max(r.b.hi[a], p[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            root.lo[a] = std::min(root.lo[a], r.b.lo[a]);
+            root.hi[a] = std::max(root.hi[a], r.b.hi[a]);
+        }
+    }
+    if (refs.empty()) return out;  // no (regular) triangle: no tree
+    nt = (uint32_t)refs.size();
+    // Pad the root cell so that hits on the hull are strictly inside it.
+    for (int a = 0; a < 3; ++a) {
+        float pad = 1e-4f * std::max(1.f, std::max(std::fabs(root.lo[a]), std::fabs(root.hi[a])));
+        root.lo[a] -= pad;
+        root.hi[a] += pad;
+    }
+
+    const auto t_start = std::chrono::steady_clock::now();
+    KDBuildParams tuned = params;  // (A/B sweeps of the heuristic's constants on the GPU box: tools/time_only.py)
+    if (const char *e = std::getenv("HRT_KD_CT")) tuned.cost_traverse = (float)atof(e);
+    if (const char *e = std::getenv("HRT_KD_CI")) tuned.cost_intersect = (float)atof(e);
+    if (const char *e = std::getenv("HRT_KD_EB")) tuned.empty_bonus = (float)atof(e);
+    Builder b(tuned, nt);
+    if (params.builder) {
+        // The replaceable step (include/hrt.h hrt_kd_builder_fn): the builder returns the nodes, ropes and flattening follow below.
+        std::vector<uint32_t> ids(nt);
+        std::vector<float> lo(3 * (size_t)nt), hi(3 * (size_t)nt);
+        for (uint32_t i = 0; i < nt; ++i) {
+            ids[i] = refs[i].id;
+            for (int a = 0; a < 3; ++a) { lo[3 * (size_t)i + a] = refs[i].b.lo[a]; hi[3 * (size_t)i + a] = refs[i].b.hi[a]; }
+        }
+        hrt_kd_build_input in;
+        in.n_refs = nt; in.ids = ids.data(); in.lo = lo.data(); in.hi = hi.data();
+        for (int a = 0; a < 3; ++a) { in.cell_lo[a] = root.lo[a]; in.cell_hi[a] = root.hi[a]; }
+        in.leaf_max = tuned.leaf_max; in.max_depth = b.max_depth;
+        in.cost_traverse = tuned.cost_traverse; in.cost_intersect = tuned.cost_intersect; in.empty_bonus = tuned.empty_bonus;
+        hrt_kd_build_output res;
+        std::memset(&res, 0, sizeof(res));
+        const int rc = params.builder(&in, &res, params.builder_user);
+        bool ok = rc == 0 && res.nodes && res.n_nodes > 0 && res.root >= 0 && (uint32_t)res.root < res.n_nodes;
+        for (uint32_t i = 0; ok && i < res.n_nodes; ++i) {
+            const hrt_kd_build_node &g = res.nodes[i];
+            if (g.axis >= 0) ok = g.axis <= 2 && g.left >= 0 && g.right >= 0 && (uint32_t)g.left < res.n_nodes && (uint32_t)g.right < res.n_nodes;
+            else ok = (uint64_t)g.first_tri + g.n_tris <= res.n_tris && (g.n_tris == 0 || res.tris);
+        }
+        if (ok) {
+            b.nodes.resize(res.n_nodes);
+            for (uint32_t i = 0; i < res.n_nodes; ++i) {
+                const hrt_kd_build_node &g = res.nodes[i];
+                BuildNode &n = b.nodes[i];
+                n.axis = g.axis; n.split = g.split; n.left = g.left; n.right = g.right;
+                for (int a = 0; a < 3; ++a) { n.cell.lo[a] = g.lo[a]; n.cell.hi[a] = g.hi[a]; }
+                if (g.axis < 0) { n.tris.assign(res.tris + g.first_tri, res.tris + g.first_tri + g.n_tris); std::sort(n.tris.begin(), n.tris.end()); }
+            }
+            b.depth_reached = res.depth;
+        }
+        const int root_from_builder = res.root;
+        std::free(res.nodes);
+        std::free(res.tris);
+        if (!ok) throw std::runtime_error("the KD builder set with hrt_host_scene_set_kd_builder failed or returned a malformed tree");
+        return finish_flat_kdtree(b, root_from_builder, root, nt, t_start);
+    }
+    unsigned threads = params.threads ? params.threads : std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("HRT_KD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    threads = std::min(threads, 16u);  // measured on the MI355X host (pool flamingo, 31 575 triangles): 1 -> 273 ms, 4 -> 177, 16 -> 112, 64 -> 173
+    int root_node;
+    if (threads > 1 && nt > 4096) {
+        std::vector<Builder::Task> tasks;
+        b.tasks = &tasks;
+        b.spawn_below = std::max<size_t>(512, nt / (4u * threads));  // SAH first cuts empty space: split by size, not by depth
+        root_node = b.build(root, refs, 0);  // the root itself (depth 0) is never a task
+        b.tasks = nullptr;
+        const auto t_top = std::chrono::steady_clock::now();
+        b.run_tasks(tasks, threads);
+        b.splice(tasks);
+        if (std::getenv("HRT_KD_VERBOSE"))
+            std::fprintf(stderr, "kd build: top %.1f ms, %zu subtree tasks\n",
+                         std::chrono::duration<double, std::milli>(t_top - t_start).count(), tasks.size());
+    } else {
+        root_node = b.build(root, refs, 0);
+    }
+    return finish_flat_kdtree(b, root_node, root, nt, t_start, threads);
 }
 
 }  // namespace hrt_host

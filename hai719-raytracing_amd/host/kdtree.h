@@ -21,6 +21,8 @@ struct KDBuildParams {
     float cost_intersect = 1.5f;
     float empty_bonus = 0.8f;   // SAH multiplier when one side is empty
     uint32_t threads = 0;       // worker threads for the subtrees below depth 5; 0 = hardware_concurrency (HRT_KD_THREADS overrides)
+    hrt_kd_builder_fn builder = nullptr;  // replaces the split search + partition (include/hrt.h; e.g. hrt_kd_build_gpu); ropes and
+    void *builder_user = nullptr;         // flattening stay here
 };
 
 struct FlatKDTree {

@@ -5,6 +5,7 @@
 //
 //   raytracer [--scene cornell_box|cornell_mesh|random_spheres|mesh_in_box|backrooms_pool]
 //             [--w 850] [--h 480] [--spp 20] [--seed 1] [--out ./rendu.ppm] [--assets DIR] [--gpu 0]
+//             [--kd gpu]                         build the KD-trees' split search on the GPU (hrt_kd_build_gpu; the same trees)
 //             [--gpus N | --devices 0,1,2,...]   image tiles across several GPUs of this node (hrt_multi_*; an ordinal may repeat)
 #include <chrono>
 #include <cstdio>
@@ -53,6 +54,7 @@ static int ray_trace_from_camera() {
 int main(int argc, char **argv) {
     std::string name = "cornell_box", assets = "assets";
     int gpu = 0;
+    bool kd_on_gpu = false;
     std::vector<int> devices;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
@@ -64,6 +66,7 @@ int main(int argc, char **argv) {
         else if (k == "--out") out_path = v;
         else if (k == "--assets") assets = v;
         else if (k == "--gpu") gpu = atoi(v.c_str());
+        else if (k == "--kd") kd_on_gpu = v == "gpu";
         else if (k == "--gpus") { devices.clear(); for (int d = 0; d < atoi(v.c_str()); ++d) devices.push_back(d); }
         else if (k == "--devices") {
             devices.clear();
@@ -75,6 +78,10 @@ int main(int argc, char **argv) {
     if (!scene.setup_by_name(name, (float)SCREENWIDTH / (float)SCREENHEIGHT, seed)) {
         std::cerr << scene.error << std::endl;
         return EXIT_FAILURE;  // the reference exit()s on a missing mesh (Mesh.cpp:12-13)
+    }
+    if (kd_on_gpu) {  // the trees' split search on the device (hrt_kd_build_gpu): the same trees, built before the scene is uploaded
+        if (hrt_init(devices.empty() ? gpu : devices[0]) != HRT_OK) { std::cerr << hrt_last_error() << std::endl; return EXIT_FAILURE; }
+        scene.kd_params.builder = hrt_kd_build_gpu;
     }
     std::unique_ptr<FlatScene> flat = scene.flatten();
     const int up = devices.empty() ? (hrt_init(gpu) != HRT_OK ? HRT_ERR_DEVICE : hrt_scene_create(&flat->desc, &device_scene))

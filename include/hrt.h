@@ -113,6 +113,36 @@ typedef struct hrt_kdunit {
     uint32_t w[4];
 } hrt_kdunit;
 
+/* The SPLIT SEARCH of the tree build as a replaceable step ("GPU (or parallel host) flattened KD build with
+ * SAH", replacing KDTree::buildTree, KDTree.cpp:87-151).  The host layer prepares the triangle references of a mesh
+ * (id + bounds, the padded root cell, the heuristic's constants), hands them to a builder, and turns the builder's nodes
+ * into the rope tree of hrt_kdunit above.  Two builders exist and give the SAME nodes: the host's own (threaded, the
+ * default) and hrt_kd_build_gpu in libhrt.so (level by level on the device); hrt_host_scene_set_kd_builder selects. */
+typedef struct hrt_kd_build_input {
+    uint32_t n_refs;
+    const uint32_t *ids;   /* triangle id of each reference                                                  */
+    const float *lo, *hi;  /* 3 floats per reference: bounds of the triangle (of the part inside the cell)   */
+    float cell_lo[3], cell_hi[3];  /* the root cell (padded hull)                                            */
+    uint32_t leaf_max, max_depth;  /* a node of <= leaf_max references, or at depth max_depth, is a leaf     */
+    float cost_traverse, cost_intersect, empty_bonus;  /* surface-area heuristic                              */
+} hrt_kd_build_input;
+typedef struct hrt_kd_build_node {
+    int32_t axis;          /* 0..2: inner node, -1: leaf                                                     */
+    float split;
+    int32_t left, right;   /* inner: indices into nodes[]                                                    */
+    float lo[3], hi[3];    /* the node's cell                                                                */
+    uint32_t first_tri, n_tris;  /* leaf: its triangle ids are tris[first_tri .. first_tri + n_tris), ascending */
+} hrt_kd_build_node;
+typedef struct hrt_kd_build_output {   /* arrays allocated by the builder with malloc(); the caller free()s them */
+    hrt_kd_build_node *nodes;
+    uint32_t n_nodes;
+    uint32_t *tris;
+    uint32_t n_tris;
+    int32_t root;
+    uint32_t depth;        /* deepest node */
+} hrt_kd_build_output;
+typedef int (*hrt_kd_builder_fn)(const hrt_kd_build_input *in, hrt_kd_build_output *out, void *user);
+
 /* IRREGULAR triangles (hai719-raytracing_amd/host/ref_tree.h).  The reference only finds a triangle through the leaves of
  * its own KD-tree (KDTree.cpp:31-69): a ray tests it when it passes the box of a leaf that holds it.  That is
  * unobservable except for triangles its builder drops below depth 100 (KDTree.cpp:101) and for
@@ -311,6 +341,12 @@ HRT_API int hrt_debug_kat(uint32_t which, const hrt_camera *cam, const float *pr
 HRT_API int hrt_debug_read_stamps(hrt_scene *scene, uint64_t out[16]);
 
 /* Output stage of main.cpp:252-262: P3 ASCII with (int)(255*min(1,c)). */
+/* The tree build's split search and partition on the GPU (a hrt_kd_builder_fn; `user` is ignored): level by level, every
+ * candidate plane of every open node evaluated in parallel with the host builder's arithmetic and tie-breaking, so the
+ * nodes -- and the flattened tree -- are identical to the host builder's (tests compare the arrays).  Exhaustive in the
+ * candidates (references x candidates per node): meant for meshes up to a few hundred thousand triangles.  Needs hrt_init. */
+HRT_API int hrt_kd_build_gpu(const hrt_kd_build_input *in, hrt_kd_build_output *out, void *user);
+
 HRT_API int hrt_write_ppm(const char *path, const float *rgb, uint32_t w, uint32_t h);
 
 /* ---- progressive rendering / resume (replaces the all-or-nothing sample loop main.cpp:188-195)

@@ -68,6 +68,11 @@ int hrt_host_scene_set_sky(hrt_host_scene *s, int32_t dark_sky);
 /* leaf_max / max_depth of the SAH builder (0 keeps the default). */
 int hrt_host_scene_set_kd_params(hrt_host_scene *s, uint32_t leaf_max, uint32_t max_depth);
 
+/* Replaces the split search of the tree build (hrt.h hrt_kd_builder_fn; NULL: the host's own threaded builder).  With
+ * libhrt.so loaded:  hrt_host_scene_set_kd_builder(s, hrt_kd_build_gpu, NULL)  builds the trees of the next flatten on the
+ * GPU; the flattened arrays are the same either way. */
+int hrt_host_scene_set_kd_builder(hrt_host_scene *s, hrt_kd_builder_fn fn, void *user);
+
 /* Builds the KD-trees and the flat description.  The pointer stays valid until
  * the next flatten / free of this scene. */
 int hrt_host_scene_flatten(hrt_host_scene *s, const hrt_scene_desc **out);

@@ -59,6 +59,69 @@ def test_c_abi_exports_every_declared_symbol(hrt):
     assert exported == dev_names, f"libhrt.so exports {sorted(set(exported) ^ set(dev_names))} beyond / short of include/hrt.h"
 
 
+def test_the_tree_build_accepts_another_builder(hrt):
+    """hrt_host_scene_set_kd_builder (include/hrt.h hrt_kd_builder_fn): the split search of the KD build is a replaceable
+    step -- libhrt.so's hrt_kd_build_gpu is one such builder (GPU test); here a builder written in Python puts every reference
+    into ONE leaf, and the host layer must rope and flatten exactly that: one four-unit leaf holding all the triangles."""
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+
+    class In(C.Structure):
+        _fields_ = [("n_refs", C.c_uint32), ("ids", C.POINTER(C.c_uint32)), ("lo", C.POINTER(C.c_float)), ("hi", C.POINTER(C.c_float)),
+                    ("cell_lo", C.c_float * 3), ("cell_hi", C.c_float * 3), ("leaf_max", C.c_uint32), ("max_depth", C.c_uint32),
+                    ("cost_traverse", C.c_float), ("cost_intersect", C.c_float), ("empty_bonus", C.c_float)]
+
+    class Node(C.Structure):
+        _fields_ = [("axis", C.c_int32), ("split", C.c_float), ("left", C.c_int32), ("right", C.c_int32), ("lo", C.c_float * 3),
+                    ("hi", C.c_float * 3), ("first_tri", C.c_uint32), ("n_tris", C.c_uint32)]
+
+    class Out(C.Structure):
+        _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("tris", C.c_void_p), ("n_tris", C.c_uint32), ("root", C.c_int32),
+                    ("depth", C.c_uint32)]
+
+    seen = {}
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(In), C.POINTER(Out), C.c_void_p)
+    def one_leaf(inp, out, user):
+        i = inp.contents
+        seen["refs"] = i.n_refs
+        seen["leaf_max"] = i.leaf_max
+        nodes = C.cast(libc.malloc(C.sizeof(Node)), C.POINTER(Node))
+        tris = C.cast(libc.malloc(4 * max(i.n_refs, 1)), C.POINTER(C.c_uint32))
+        for k in range(i.n_refs):
+            tris[i.n_refs - 1 - k] = i.ids[k]          # (any order: the host layer sorts a leaf's ids)
+        n = nodes[0]
+        n.axis = -1; n.split = 0.0; n.left = n.right = -1; n.first_tri = 0; n.n_tris = i.n_refs
+        for a in range(3):
+            n.lo[a] = i.cell_lo[a]; n.hi[a] = i.cell_hi[a]
+        o = out.contents
+        o.nodes = C.cast(nodes, C.c_void_p); o.n_nodes = 1; o.tris = C.cast(tris, C.c_void_p); o.n_tris = i.n_refs; o.root = 0; o.depth = 0
+        return 0
+
+    s = hrt.HostScene().setup("cornell_mesh", 1.0, 1)
+    s.set_kd_builder(one_leaf)
+    desc = s.flatten()
+    d = C.cast(desc, C.POINTER(SceneDesc)).contents
+    m = C.cast(d.meshes, C.POINTER(MeshDesc))[0]
+    assert seen["refs"] == m.n_leaf_tris and seen["leaf_max"] == 4
+    assert m.n_kd_units == 4 and m.kd_root == 0x80000000                    # one leaf, four 16-byte units
+    units = np.ctypeslib.as_array(C.cast(m.kd_units, C.POINTER(C.c_uint32)), shape=(4, 4))
+    leaf = np.ctypeslib.as_array(C.cast(m.leaf_tris, C.POINTER(C.c_uint32)), shape=(m.n_leaf_tris,))
+    assert units[0, 3] == 0 and units[1, 3] == m.n_leaf_tris and (units[2] == 0xFFFFFFFF).all() and (units[3, :2] == 0xFFFFFFFF).all()
+    assert (np.diff(leaf.astype(np.int64)) > 0).all()                       # ascending, none twice
+    s.set_kd_builder(None)                                                    # and back to the host's own builder
+    d2 = C.cast(s.flatten(), C.POINTER(SceneDesc)).contents
+    assert C.cast(d2.meshes, C.POINTER(MeshDesc))[0].n_kd_units > 4
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(In), C.POINTER(Out), C.c_void_p)
+    def broken(inp, out, user):
+        return -1
+    s.set_kd_builder(broken)
+    with pytest.raises(hrt.HrtError, match="builder"):
+        s.flatten()
+
+
 def test_device_library_fails_loudly_without_init(hrt):
     """No silent fallback: before hrt_init (or with no GPU) the product path returns an error code."""
     lib = hrt.device_lib()
