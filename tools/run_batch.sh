@@ -1,1 +1,4 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_kdbuild.py -m gpu -q -x -s > gpurun_out/kd_tests.log 2>&1; tail -25 gpurun_out/kd_tests.log
+# batch for one gpurun call: the GPU suite, smoke, the profiles of every configuration, the default bench
+timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests.log 2>&1; tail -4 gpurun_out/gpu_tests.log
+python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
+bash tools/profile.sh r03 > gpurun_out/profile_r03.log 2>&1; grep -E "failed|==" gpurun_out/profile_r03.log | cut -c1-200
