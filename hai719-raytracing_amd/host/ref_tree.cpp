@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 
 namespace hrt_host {
 namespace {
@@ -17,10 +19,19 @@ struct Analysis {
     std::vector<std::vector<uint32_t>> leaf_tris;
     std::vector<Bounds> leaf_box;
     uint32_t depth_reached = 0;
+    // The reference's rule copies a straddling triangle to BOTH sides and only stops at 40 triangles, at equal halves or below
+    // depth 100: on a soup of large overlapping triangles nothing ever separates and the recursion doubles per level -- the
+    // reference itself never finishes on such a mesh (2^100 nodes).  The analysis follows it only as far as a finished
+    // reference tree could plausibly go (a tree of depth ~25 that keeps ~4 copies of every triangle handles ~100 nt
+    // references in all) and then says so instead of hanging.
+    uint64_t work = 0, budget = 0;
+    bool exhausted = false;
 
     // KDTree::buildTree, KDTree.cpp:100-151.  `tris` by value semantics of the reference's vectors; box = the node's AABB.
     void partition(const std::vector<uint32_t> &tris, const Bounds &box, unsigned depth) {
-        if (tris.empty()) return;
+        if (tris.empty() || exhausted) return;
+        work += tris.size();
+        if (work > budget) { exhausted = true; return; }
         if (depth > 100u) {                  // KDTREE_MAX_DEPTH: the subtree is not built, its triangles are lost HERE
             for (uint32_t t : tris) dropped[t] = 1;
             return;
@@ -74,7 +85,13 @@ RefTreeAnalysis analyse_reference_tree(const float *positions, uint32_t nv, cons
     for (uint32_t t = 0; t < nt; ++t) all[t] = t;
     Bounds root;
     for (int a = 0; a < 3; ++a) { root.lo[a] = aabb_min[a]; root.hi[a] = aabb_max[a]; }
+    A.budget = 400ull * nt + 10000000ull;
     A.partition(all, root, 0u);
+    if (A.exhausted)
+        throw std::runtime_error("mesh of " + std::to_string(nt) + " triangles: the reference's KD builder (KDTree.cpp:100-151: median cut, straddlers copied to both "
+                                 "sides, leaves of 40, depth 100) does not terminate on it -- " + std::to_string(A.work) + " triangle references by depth " +
+                                 std::to_string(A.depth_reached) + " and growing; its triangles overlap too much to be separated, and the reference cannot "
+                                 "render this mesh either");
     out.ref_leaves = (uint32_t)A.leaf_box.size();
     out.ref_depth = A.depth_reached;
 

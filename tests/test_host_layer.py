@@ -59,6 +59,30 @@ def test_c_abi_exports_every_declared_symbol(hrt):
     assert exported == dev_names, f"libhrt.so exports {sorted(set(exported) ^ set(dev_names))} beyond / short of include/hrt.h"
 
 
+def test_a_mesh_the_reference_builder_cannot_finish_is_refused_not_hung(hrt):
+    """The host layer follows the reference's own KD partition (KDTree.cpp:100-151) to learn which triangles its tree drops
+    or mis-hits (host/ref_tree.cpp).  That rule copies straddling triangles to both sides down to depth 100: on a soup of large
+    overlapping triangles it doubles per level and the reference itself never finishes.  Found by tools/fuzz_exact.py (round 3:
+    flatten hung); the analysis now has a work budget and flatten fails with a message, in well under a minute."""
+    import time
+    rng = np.random.default_rng(1)
+    nt = 700
+    pos = rng.normal(scale=1.0, size=(3 * nt, 3)).astype(np.float32)
+    tri = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+    s = hrt.HostScene()
+    s.add_mesh(pos, tri, hrt.Material.make())
+    t0 = time.time()
+    with pytest.raises(hrt.HrtError, match="does not terminate"):
+        s.flatten()
+    assert time.time() - t0 < 30
+    # small, well-separated triangles of the same count are fine
+    s2 = hrt.HostScene()
+    centres = rng.uniform(-3, 3, size=(nt, 1, 3)).astype(np.float32)
+    s2.add_mesh((centres + 0.05 * rng.normal(size=(nt, 3, 3)).astype(np.float32)).reshape(-1, 3), tri, hrt.Material.make())
+    s2.flatten()
+    assert s2.kd_stats(0)["leaf_tri_refs"] >= nt * 0.9
+
+
 def test_the_tree_build_accepts_another_builder(hrt):
     """hrt_host_scene_set_kd_builder (include/hrt.h hrt_kd_builder_fn): the split search of the KD build is a replaceable
     step -- libhrt.so's hrt_kd_build_gpu is one such builder (GPU test); here a builder written in Python puts every reference

@@ -1,0 +1,105 @@
+"""Randomised search for a pixel that a filter, the pruning or the KD walk changes (GPU box):
+
+    python tools/fuzz_exact.py [scenes] [first seed]
+
+Every scene is random -- 0-130 spheres with radii over four decades (some enclosing the camera, some moving, mirror / glass /
+diffuse / emissive), 1-70 squares (axis-aligned walls and tilted, glass and emissive ones), 0-3 meshes of random triangles (slivers
+included), 0-2 point lights, dark or gradient sky -- and is rendered twice by the streaming kernel: the shipped build and the proof
+build (HRT_FLAG_EXACT_ONLY: no filter, no pruning, IEEE divisions; every third scene also HRT_FLAG_MESH_BRUTE: no tree).  The two
+frames must be identical; the lane-per-pixel kernel's frame too.  Prints one line per scene and a summary; exits non-zero on the
+first difference."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+hrt = importlib.import_module("hai719-raytracing_amd")
+hrt.init(0)
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+M = hrt.Material.make
+w, h, spp = 480, 270, 3
+
+
+def material(rng, allow_emissive=True):
+    kind = rng.integers(0, 6)
+    typ = hrt.MAT_GLASS if kind == 0 else (hrt.MAT_MIRROR if kind == 1 else hrt.MAT_DIFFUSE)
+    kw = dict(albedo=tuple(rng.uniform(0.0, 1.0, 3)) if rng.random() > 0.1 else (0.0, 0.0, 0.0), type=typ,
+              transparency=float(rng.choice([0.0, 0.3, 0.9])), index_medium=float(rng.uniform(1.05, 2.0)),
+              motion=(0.0, float(rng.uniform(0, 1.0)), float(rng.uniform(-0.5, 0.5))) if rng.random() < 0.25 else (0, 0, 0))
+    if allow_emissive and kind == 5:
+        kw.update(emissive=1, light_color=tuple(rng.uniform(0.2, 1.0, 3)), light_intensity=float(rng.uniform(1, 12)))
+    return M(**kw)
+
+
+def scene(seed):
+    rng = np.random.default_rng(seed)
+    s = hrt.HostScene()
+    s.set_sky(bool(rng.integers(0, 2)))
+    for _ in range(int(rng.integers(0, 3))):
+        s.add_light(tuple(rng.uniform((-6, 2, -8), (6, 10, 4))), float(rng.uniform(0.2, 3.0)), tuple(rng.uniform(0.3, 1.0, 3)))
+    ns = int(rng.choice([0, 1, 2, 7, 8, 9, 31, 64, 65, 127, 128, 130]))
+    for _ in range(ns):
+        r = float(10.0 ** rng.uniform(-2.5, 1.3))
+        c = rng.uniform((-15, -3, -45), (15, 8, 8))
+        if rng.random() < 0.03:
+            c, r = np.array([0.0, 0.0, 5.0]) + rng.normal(size=3), float(rng.uniform(3, 40))   # around the camera
+        s.add_sphere(tuple(float(x) for x in c), r, material(rng))
+    nq = int(rng.choice([1, 2, 6, 11, 28, 33, 64, 70]))
+    if rng.random() < 0.7:   # a room of axis-aligned walls first
+        e = float(rng.uniform(3, 9))
+        for (p, r_, u_) in (((-e, -2, -2 * e), (1, 0, 0), (0, 0, 1)), ((-e, 2 * e - 2, -2 * e), (0, 0, 1), (1, 0, 0)), ((-e, -2, -2 * e), (0, 1, 0), (1, 0, 0)),
+                            ((-e, -2, -2 * e), (0, 0, 1), (0, 1, 0)), ((e, -2, -2 * e), (0, 1, 0), (0, 0, 1))):
+            s.add_quad(p, r_, u_, 2 * e, 2 * e, material(rng))
+    for i in range(nq):
+        c = rng.uniform((-6, -2, -12), (6, 5, 1))
+        if rng.random() < 0.5:
+            ax = int(rng.integers(0, 3)); r_ = np.eye(3)[(ax + 1) % 3]; u_ = np.eye(3)[(ax + 2) % 3]
+            if rng.random() < 0.5: r_, u_ = u_, r_
+        else:
+            r_ = rng.normal(size=3); u_ = np.cross(r_, rng.normal(size=3))
+        s.add_quad(tuple(float(x) for x in c), tuple(float(x) for x in r_), tuple(float(x) for x in u_), float(10.0 ** rng.uniform(-1.5, 0.9)),
+                   float(10.0 ** rng.uniform(-1.5, 0.9)), material(rng))
+    for _ in range(int(rng.integers(0, 4))):
+        nt = int(rng.choice([1, 4, 60, 700]))
+        base = rng.uniform((-4, -1.5, -9), (4, 3, -1))
+        spread = float(rng.uniform(0.2, 1.5))
+        centres = rng.normal(scale=spread, size=(nt, 1, 3))
+        size = spread * float(rng.choice([1.0, 0.3, 0.08]))  # (a soup of LARGE overlapping triangles is refused by flatten: the reference's builder cannot finish it)
+        pos = (base + centres + rng.normal(scale=size, size=(nt, 3, 3))).reshape(-1, 3).astype(np.float32)
+        if rng.random() < 0.3:
+            k = rng.random(nt) < 0.2   # some slivers
+            v = pos.reshape(nt, 3, 3)
+            v[k, 1] = v[k, 0] + (v[k, 2] - v[k, 0]) * np.float32(0.5) + np.float32(1e-6)
+            pos = v.reshape(-1, 3)
+        tri = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+        s.add_mesh(pos, tri, material(rng, allow_emissive=False), face_colors=rng.uniform(0, 1, (nt, 3)).astype(np.float32) if rng.random() < 0.5 else None)
+    return s, ns, nq
+
+
+bad = 0
+refused = 0
+for k in range(n_scenes):
+    seed = seed0 + k
+    host, ns, nq = scene(seed)
+    try:
+        desc = host.flatten()
+    except hrt.HrtError as e:
+        refused += 1
+        print(f"seed {seed}: refused by flatten ({str(e)[:90]}...)", flush=True)
+        continue
+    dev = hrt.DeviceScene(desc)
+    cam = hrt.default_camera(w / h)
+    a, _ = dev.render(cam, w, h, spp, seed=seed, flags=hrt.FLAG_STREAM_KERNEL)
+    exact = hrt.FLAG_STREAM_KERNEL | hrt.FLAG_EXACT_ONLY | (hrt.FLAG_MESH_BRUTE if k % 3 == 0 else 0)
+    b, _ = dev.render(cam, w, h, spp, seed=seed, flags=exact)
+    c, _ = dev.render(cam, w, h, spp, seed=seed, flags=hrt.FLAG_WAVE_KERNEL)
+    same = np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+    print(f"seed {seed}: {ns} spheres, {nq}+ squares: {'identical' if same else 'DIFFERENT'}  (mean {float(np.nanmean(a)):.4f})", flush=True)
+    if not same:
+        d = (a != b).any(axis=2) | (a != c).any(axis=2)
+        print("   pixels", int(d.sum()), "first", np.argwhere(d)[:5].tolist(), "shipped vs exact", int((a != b).any(axis=2).sum()), "vs lane-per-pixel", int((a != c).any(axis=2).sum()))
+        bad += 1
+        break
+    dev.close()
+print(f"{k + 1} random scenes ({refused} refused by the host layer), {bad} with a difference")
+sys.exit(1 if bad else 0)
