@@ -613,14 +613,15 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         // reference boxes (exact AABB.h:48-65 arithmetic) to learn whether the reference would have tested it at all.
         // Entries, 2 rows each, threaded depth-first:
         //   inner   {lo', HRT_EXC_INNER} {hi', skip}     padded bounds of a subtree: only culls
-        //   leaf    {cull lo, soup slot} {cull hi, nb}   then nb box entries {box lo, 0} {box hi, 0} the walk jumps over
+        //   leaf    {cull lo, soup slot} {cull hi, nb}   then nb box entries {box lo, last} {box hi, 0} the walk jumps over; the boxes of one
+        //           reference leaf follow each other (`last` = 1 on the final one) and must ALL be passed for that leaf to count
         // The cull box of a well-conditioned triangle is its own padded bounds (an accepted hit point lies in the triangle up to
         // the rounding of the barycentric solve, ~1e-7 / sin^2); a sliver's barycentric test accepts points anywhere in its
         // plane, so its cull box is the padded union of its reference boxes (a ray that passes none of them is not tested).
         dm.exc_base = (uint32_t)(exceptions.size() / 2);
         dm.n_exc = 0;
         if (M.n_exceptions) {
-            struct Group { float lo[3], hi[3]; uint32_t tri; std::vector<std::array<float, 6>> boxes; };
+            struct Group { float lo[3], hi[3]; uint32_t tri; std::vector<std::array<float, 7>> boxes; };  // box: lo, hi, 1.f on the last box of its leaf
             std::vector<Group> groups;
             {
                 std::vector<uint32_t> order(M.n_exceptions);
@@ -630,21 +631,26 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                 }
                 static_assert(offsetof(hrt_tri_exception, box_max) == offsetof(hrt_tri_exception, box_min) + 12, "box_min and box_max are contiguous");
                 auto box_cmp = [&](uint32_t x, uint32_t y) { return std::memcmp(M.exceptions[x].box_min, M.exceptions[y].box_min, 24); };
-                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-                    return M.exceptions[x].triangle < M.exceptions[y].triangle || (M.exceptions[x].triangle == M.exceptions[y].triangle && box_cmp(x, y) < 0);
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {   // by triangle, then by reference leaf (the caller's order inside a leaf)
+                    const hrt_tri_exception &ex = M.exceptions[x], &ey = M.exceptions[y];
+                    return ex.triangle < ey.triangle || (ex.triangle == ey.triangle && ex.group < ey.group);
                 });
                 for (size_t q = 0; q < order.size(); ++q) {
                     const hrt_tri_exception &e = M.exceptions[order[q]];
-                    if (groups.empty() || groups.back().tri != e.triangle) {
+                    const bool same_tri = !groups.empty() && groups.back().tri == e.triangle;
+                    const bool same_leaf = same_tri && q > 0 && M.exceptions[order[q - 1]].group == e.group;
+                    if (!same_tri) {
                         groups.emplace_back();
                         groups.back().tri = e.triangle;
-                    } else if (box_cmp(order[q - 1], order[q]) == 0) {
-                        continue;  // the same pair twice
                     }
-                    std::array<float, 6> bx;
+                    if (same_leaf && box_cmp(order[q - 1], order[q]) == 0) continue;  // the same box twice
+                    if (!same_leaf && !groups.back().boxes.empty()) groups.back().boxes.back()[6] = 1.f;  // the previous leaf's boxes end here
+                    std::array<float, 7> bx;
                     std::memcpy(bx.data(), e.box_min, 24);
+                    bx[6] = 0.f;
                     groups.back().boxes.push_back(bx);
                 }
+                for (Group &g : groups) g.boxes.back()[6] = 1.f;
                 for (Group &g : groups) {
                     double c[3][3];
                     for (int j = 0; j < 3; ++j) {
@@ -662,7 +668,9 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                         if (own_bounds) {
                             for (int j = 0; j < 3; ++j) { lo = std::min(lo, c[j][a]); hi = std::max(hi, c[j][a]); }
                         } else {
-                            for (const auto &bx : g.boxes) { lo = std::min(lo, (double)bx[a]); hi = std::max(hi, (double)bx[3 + a]); }
+                            for (const auto &bx : g.boxes) {  // (AABB::intersects reads a box's faces in either order: a cut outside its node leaves one)
+                                lo = std::min(lo, (double)std::min(bx[a], bx[3 + a])); hi = std::max(hi, (double)std::max(bx[a], bx[3 + a]));
+                            }
                         }
                         double ext = 0.0;
                         for (int x = 0; x < 3; ++x) ext = std::max(ext, std::max(std::fabs(e1[x]), std::fabs(e2[x])));
@@ -686,7 +694,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
                         out.push_back(make_float4(b.lo[0], b.lo[1], b.lo[2], as_float(slot)));
                         out.push_back(make_float4(b.hi[0], b.hi[1], b.hi[2], as_float((uint32_t)b.boxes.size())));
                         for (const auto &bx : b.boxes) {
-                            out.push_back(make_float4(bx[0], bx[1], bx[2], 0.f));
+                            out.push_back(make_float4(bx[0], bx[1], bx[2], as_float(bx[6] != 0.f ? 1u : 0u)));  // .w: 1 = the last box of its reference leaf
                             out.push_back(make_float4(bx[3], bx[4], bx[5], 0.f));
                         }
                         return;

@@ -447,12 +447,15 @@ __device__ __forceinline__ bool mesh_exceptions_walk(cscene S, EP ex_all, MP M, 
         if (!EXACT && gate_filter(b, ray, inv) < 0) continue;  // the cull box (padded; never in the proof builds)
         float t = best_t, u = 0.f, v = 0.f;
         if (!tri_test(sp, first, ray, t, u, v)) continue;      // Triangle.h:77-126 and the leaf's strict `<` (KDTree.cpp:44)
-        bool tested = false;  // would the reference have tested it: does the ray pass a reference leaf that holds it (AABB.h:48-65)
+        // would the reference have tested it: does the ray reach a reference leaf that holds it -- pass that leaf's box and the boxes
+        // of the ancestors that stick into it (AABB.h:48-65 each; the boxes of one leaf follow each other, .w = 1 on the last)
+        bool tested = false, reach = true;
         for (uint32_t j = 0; j < cnt && !tested; ++j) {
             const float4 bl = ld(ex, 2u * (boxes + j)), bh = ld(ex, 2u * (boxes + j) + 1u);
             GateBox rb;
             rb.l[0] = bl.x; rb.l[1] = bl.y; rb.l[2] = bl.z; rb.h[0] = bh.x; rb.h[1] = bh.y; rb.h[2] = bh.z;
-            tested = mesh_gate_box<EXACT>(rb, ray, inv);
+            if (reach) reach = mesh_gate_box<EXACT>(rb, ray, inv);
+            if (__float_as_uint(bl.w) != 0u) { tested = reach; reach = true; }
         }
         if (tested) { best_t = t; bu = u; bv = v; best_tri = first; found = true; }
     }

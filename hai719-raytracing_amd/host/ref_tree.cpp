@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -18,6 +20,30 @@ struct Analysis {
     std::vector<uint8_t> dropped;            // lost by some subtree below depth 100
     std::vector<std::vector<uint32_t>> leaf_tris;
     std::vector<Bounds> leaf_box;
+    std::vector<std::vector<Bounds>> leaf_gate;  // per leaf: the boxes a ray must ALL pass to reach it (see gate_of)
+    std::vector<Bounds> path;                    // the boxes from the root to the node in hand
+
+    // KDTree::Node::intersect descends through `aabb.intersects(ray)` of EVERY node on the way (KDTree.cpp:32).  A child's box is
+    // its parent's with one face moved to the cutting plane -- inside the parent when the plane is, and then whoever passes the
+    // child passes the parent (AABB::intersects is monotone in the faces).  But cut() takes the median of UNCLIPPED triangle
+    // bounds (:87-98): the plane can lie outside the node, one child then CONTAINS its parent and sticks out of it, and a ray
+    // through the part that sticks out reaches the leaf's box without reaching the leaf.  So a leaf is reached through its own
+    // box and every ancestor box that does not contain a box already kept (as AABB::intersects reads a box: faces in either order).
+    static bool contains(const Bounds &outer, const Bounds &inner) {
+        for (int a = 0; a < 3; ++a)
+            if (!(std::min(outer.lo[a], outer.hi[a]) <= std::min(inner.lo[a], inner.hi[a]) && std::max(outer.lo[a], outer.hi[a]) >= std::max(inner.lo[a], inner.hi[a])))
+                return false;
+        return true;
+    }
+    std::vector<Bounds> gate_of() const {
+        std::vector<Bounds> keep{path.back()};
+        for (size_t k = path.size() - 1; k-- > 0;) {
+            bool implied = false;
+            for (const Bounds &b : keep) implied = implied || contains(path[k], b);
+            if (!implied) keep.push_back(path[k]);
+        }
+        return keep;
+    }
     uint32_t depth_reached = 0;
     // The reference's rule copies a straddling triangle to BOTH sides and only stops at 40 triangles, at equal halves or below
     // depth 100: on a soup of large overlapping triangles nothing ever separates and the recursion doubles per level -- the
@@ -26,6 +52,7 @@ struct Analysis {
     // references in all) and then says so instead of hanging.
     uint64_t work = 0, budget = 0;
     bool exhausted = false;
+    uint32_t outside_splits = 0;
 
     // KDTree::buildTree, KDTree.cpp:100-151.  `tris` by value semantics of the reference's vectors; box = the node's AABB.
     void partition(const std::vector<uint32_t> &tris, const Bounds &box, unsigned depth) {
@@ -37,7 +64,8 @@ struct Analysis {
             return;
         }
         depth_reached = std::max(depth_reached, depth);
-        auto leaf = [&]() { leaf_tris.push_back(tris); leaf_box.push_back(box); };
+        struct PathGuard { std::vector<Bounds> &p; PathGuard(std::vector<Bounds> &p_, const Bounds &b) : p(p_) { p.push_back(b); } ~PathGuard() { p.pop_back(); } } on_path(path, box);
+        auto leaf = [&]() { leaf_tris.push_back(tris); leaf_box.push_back(box); leaf_gate.push_back(gate_of()); };
         if (tris.size() <= 40u) { leaf(); return; }   // KDTREE_TRIANGLES_PER_LEAF
         // cut(), KDTree.cpp:87-98: median of the triangles' lower bounds on axis depth % 3, plus EPSILON (a double), as float
         const int axis = (int)(depth % 3u);
@@ -45,6 +73,7 @@ struct Analysis {
         for (size_t i = 0; i < tris.size(); ++i) mins[i] = tb[tris[i]].lo[axis];
         std::sort(mins.begin(), mins.end());
         const float position = (float)((double)mins[mins.size() / 2] + HRT_EPSILON);
+        if (!(position > box.lo[axis] && position < box.hi[axis])) ++outside_splits;  // (the cut uses UNCLIPPED triangle bounds)
         std::vector<uint32_t> left, right;
         for (uint32_t t : tris) {            // :129-140, comparisons in double as written
             if ((double)tb[t].hi[axis] <= (double)position - HRT_EPSILON) left.push_back(t);
@@ -92,6 +121,7 @@ RefTreeAnalysis analyse_reference_tree(const float *positions, uint32_t nv, cons
                                  "sides, leaves of 40, depth 100) does not terminate on it -- " + std::to_string(A.work) + " triangle references by depth " +
                                  std::to_string(A.depth_reached) + " and growing; its triangles overlap too much to be separated, and the reference cannot "
                                  "render this mesh either");
+    if (std::getenv("HRT_REF_VERBOSE")) std::fprintf(stderr, "ref tree: %u triangles, %zu leaves, depth %u, %u splits outside their node\n", nt, A.leaf_box.size(), A.depth_reached, A.outside_splits);
     out.ref_leaves = (uint32_t)A.leaf_box.size();
     out.ref_depth = A.depth_reached;
 
@@ -126,12 +156,15 @@ RefTreeAnalysis analyse_reference_tree(const float *positions, uint32_t nv, cons
     for (size_t l = 0; l < A.leaf_box.size(); ++l)
         for (uint32_t t : A.leaf_tris[l])
             if (out.irregular[t] && !dead[t]) {
-                hrt_tri_exception e;
-                e.triangle = t;
-                for (int a = 0; a < 3; ++a) { e.box_min[a] = A.leaf_box[l].lo[a]; e.box_max[a] = A.leaf_box[l].hi[a]; }
-                out.exceptions.push_back(e);
+                ++out.n_pairs;
+                for (const Bounds &b : A.leaf_gate[l]) {  // the leaf's own box first, then the ancestors that stick in
+                    hrt_tri_exception e;
+                    e.triangle = t;
+                    e.group = (uint32_t)l;
+                    for (int a = 0; a < 3; ++a) { e.box_min[a] = b.lo[a]; e.box_max[a] = b.hi[a]; }
+                    out.exceptions.push_back(e);
+                }
             }
-    out.n_pairs = (uint32_t)out.exceptions.size();
     return out;
 }
 

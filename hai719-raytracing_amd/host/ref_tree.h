@@ -30,8 +30,9 @@ namespace hrt_host {
 
 struct RefTreeAnalysis {
     std::vector<uint8_t> irregular;             // per triangle: 1 = keep out of the SAH tree
-    std::vector<hrt_tri_exception> exceptions;  // (triangle, reference leaf box) pairs of the live irregular triangles (include/hrt.h)
-    uint32_t n_dropped = 0, n_slivers = 0, n_dead = 0, n_pairs = 0;  // statistics (n_pairs: leaf entries of `exceptions`)
+    std::vector<hrt_tri_exception> exceptions;  // (triangle, reference leaf, box) entries of the live irregular triangles (include/hrt.h): one box per
+                                                // leaf, more where an ancestor's box does not contain the leaf's (`group` = the leaf)
+    uint32_t n_dropped = 0, n_slivers = 0, n_dead = 0, n_pairs = 0;  // statistics (n_pairs: (triangle, leaf) pairs)
     uint32_t ref_leaves = 0, ref_depth = 0;
 };
 

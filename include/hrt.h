@@ -149,11 +149,17 @@ typedef int (*hrt_kd_builder_fn)(const hrt_kd_build_input *in, hrt_kd_build_outp
  * near-degenerate slivers, whose barycentric test (Triangle.h:62-75) accepts phantom points far outside the triangle.
  * Those triangles are kept OUT of the flattened tree (not listed in leaf_tris) and tested exactly when the reference
  * would: when AABB::intersects (AABB.h:48-65) passes for the box of one of the reference leaves that hold them.
- * One entry per (triangle, reference leaf box) pair, in any order; hrt_scene_create groups them by triangle under a small
- * bounding hierarchy: a ray tests such a triangle at most once, and asks its boxes only for a hit closer than the best. */
+ * One entry per (triangle, reference leaf, box) -- a leaf is one box, or a few when ancestors stick in (`group`) -- in any
+ * order; hrt_scene_create groups them by triangle under a small bounding hierarchy: a ray tests such a triangle at most once,
+ * and asks its boxes only for a hit closer than the best. */
 typedef struct hrt_tri_exception {
     uint32_t triangle;           /* triangle id of the mesh */
     float box_min[3], box_max[3];
+    uint32_t group;              /* which reference leaf this box belongs to: the entries of one triangle with the same group are the
+                                    boxes the ray must ALL pass to reach that leaf -- the leaf's own box, and those of its ancestors
+                                    that do not contain it (the reference cuts a node at the median of UNCLIPPED triangle bounds,
+                                    KDTree.cpp:87-98: the plane can lie outside the node and a child then sticks out of its parent).
+                                    The triangle is tested when some group passes entirely.                                        */
 } hrt_tri_exception;
 
 typedef struct hrt_mesh {

@@ -359,9 +359,14 @@ inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 TriHit rope_tree_intersect(const OMesh &m, const Ray &ray, Counters *cnt) {
     TriHit best;
     const hrt_mesh &s = *m.src;
-    for (uint32_t k = 0; k < s.n_exceptions; ++k) {  // irregular triangles: through their reference leaf boxes (include/hrt.h)
-        const hrt_tri_exception &e = s.exceptions[k];
-        if (!aabb_intersects(e.box_min, e.box_max, ray)) continue;
+    for (uint32_t k = 0; k < s.n_exceptions;) {  // irregular triangles: through their reference leaves (include/hrt.h): the entries of one
+        const hrt_tri_exception &e = s.exceptions[k];  // (triangle, group) are the boxes that must ALL be passed to reach that leaf
+        bool reach = true;
+        uint32_t k1 = k;
+        for (; k1 < s.n_exceptions && s.exceptions[k1].triangle == e.triangle && s.exceptions[k1].group == e.group; ++k1)
+            reach = reach && aabb_intersects(s.exceptions[k1].box_min, s.exceptions[k1].box_max, ray);
+        k = k1;
+        if (!reach) continue;
         TriHit h = leaf_triangle(m, e.triangle, ray, cnt);
         if (h.t < best.t) { best = h; best.tIndex = e.triangle; }
     }

@@ -237,12 +237,12 @@ def test_irregular_triangles_are_found_and_kept_out_of_the_tree(hrt, oracle):
     assert (st["dead"], st["slivers"], st["dropped"], st["entries"]) == (64, 0, 0, 0)
     host = hrt.HostScene().setup("mesh_in_box", 16 / 9, 1); desc = host.flatten()
     st = host.irregular_stats(0)
-    assert (st["dead"], st["slivers"], st["dropped"], st["pairs"]) == (0, 2, 0, 2) and st["entries"] == 2
+    assert (st["dead"], st["slivers"], st["dropped"], st["pairs"]) == (0, 2, 0, 2) and st["entries"] >= 2   # (a leaf is one box, or a few: hrt_tri_exception::group)
     d = C.cast(desc, C.POINTER(SceneDesc)).contents
     m = C.cast(d.meshes, C.POINTER(MeshDesc))[0]
     leaf = np.ctypeslib.as_array(C.cast(m.leaf_tris, C.POINTER(C.c_uint32)), shape=(m.n_leaf_tris,))
-    exc = np.ctypeslib.as_array(C.cast(m.exceptions, C.POINTER(C.c_uint32)), shape=(m.n_exceptions, 7))  # {triangle, box min, box max}
-    tri = exc[:, 0]
+    exc = np.ctypeslib.as_array(C.cast(m.exceptions, C.POINTER(C.c_uint32)), shape=(m.n_exceptions, 8))  # {triangle, box min, box max, group}
+    tri = np.unique(exc[:, 0])
     assert len(tri) == 2 and not np.isin(tri, leaf).any()           # irregular triangles are not in any leaf
     assert len(np.unique(leaf)) == m.n_triangles - 2                # everything else is
     host = hrt.HostScene().setup("raccoon", 16 / 9, 1); host.flatten()
