@@ -81,6 +81,9 @@
                                        // consumes something finite (a path has <= 6 hit visits; a walk crosses <= HRT_WALK_CELLS cells of a
                                        // tree hrt_scene_create has checked, and a leaf's cursor only advances), so the bound does not depend
                                        // on how long a legal walk is -- a leaf of 65 534 triangles is ~5 500 T visits of one path, all progress
+#ifndef HRT_SP_WAIT_SECONDS
+#define HRT_SP_WAIT_SECONDS 900ull     // how long a wave waits for the other waves of a cycle before it declares the launch dead (a watchdog)
+#endif
 #ifndef HRT_SP_GIVEUP_AFTER
 #define HRT_SP_GIVEUP_AFTER 0u         // test build only (Makefile, libhrt_var_bound.so: 3): give up after that many serial sections whatever
 #endif                                 // they ran, to exercise the path on which a launch reports HRT_ERR_DEVICE
@@ -520,11 +523,15 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
             const unsigned long long dbg_q0 = __builtin_readcyclecounter();
 #endif
             uint32_t spins = 0, aborted = 0;
+            const unsigned long long wait_t0 = __builtin_amdgcn_s_memrealtime();
             while (SP_UNI(__hip_atomic_load(&C.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < kcyc[st]) {
                 __builtin_amdgcn_s_sleep(8);
                 aborted = SP_UNI(__hip_atomic_load(&SH.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (aborted) break;
-                if (++spins > (1u << 24)) {  // seconds: nothing legitimate takes that long
+                // A watchdog, by the 100 MHz real-time counter: the other waves of the cycle may legitimately work for SECONDS on a
+                // single chunk (a lit scene whose meshes carry millions of reference-box entries: tools/fuzz_exact.py seed 1056 took
+                // 132 s per frame and tripped the former bound of 2^24 spins, ~4 s) -- so this only ends a wait that nothing could explain
+                if ((++spins & 1023u) == 0u && (spins >> 10) > 16u && __builtin_amdgcn_s_memrealtime() - wait_t0 > 100000000ull * HRT_SP_WAIT_SECONDS) {
                     if (lane == 0) {
                         if (R.stamps) { __hip_atomic_store(R.stamps + 15, 0xDEADull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); R.stamps[14] = 3; }
                         __hip_atomic_store(&SH.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
