@@ -392,3 +392,30 @@ def test_threaded_kd_build_emits_the_same_tree(hrt, monkeypatch):
         u, l, r = tree(threads)
         assert r == r1 and np.array_equal(u, u1) and np.array_equal(l, l1)
     assert len(u1) > 100000
+
+
+def test_committed_profiles_are_of_the_committed_kernel_sources():
+    """bench.py prices the dominant kernel with counters from profiles/r03_<cfg>_pmc.json and refuses a profile measured on
+    other kernel sources.  So the summaries in the tree must carry the hash of the sources in the
+    tree -- otherwise the bench line of this commit would come without its roofline -- and bench.py and tools/pmc_summary.py must
+    hash the same files the same way."""
+    import importlib.util
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    sha = bench.source_sha16()
+    assert sha == pmc.source_sha16()
+    for cfg, scene, w, h, spp in [("cfg2_256", bench.SCENE, bench.W, bench.H, bench.SPP)] + [(t, n, w_, h_, s_) for t, n, w_, h_, s_ in bench.OTHER_CONFIGS]:
+        summary, why = bench.committed_pmc(cfg, scene, w, h, spp)
+        assert summary is not None, f"profiles/r03_{cfg}_pmc.json: {why}"
+        d = summary["derived"]
+        assert d["fabric_bytes_per_launch"] > 0 and 0 < d["valu_busy_frac"] <= 1 and 0 < d["valu_lane_utilisation"] <= 1
+        assert abs(d["fetch_factor"] - 2.0) < 0.05 and abs(d["write_factor"] - 1.0) < 0.05   # what profiles/r03_traffic_calibration.json measured for this pattern
+    means = bench.committed_frame_means()
+    assert len(means) == 6 and all(0 < v < 1 for v in means.values())
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic_calibration.json")))
+    for pool in cal["pools"].values():
+        assert abs(pool["fetch_factor_vs_line_bytes"] - 2.0) < 0.1 and abs(pool["read_requests_per_lane_visit"]["128B"] - 1.0) < 0.05
