@@ -27,6 +27,9 @@ Rank 0 prints ONE JSON line.  What its evidence keys mean:
   valu          the bound that actually binds: SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES summed over SIMDs), i.e. the share
                 of SIMD cycles that issued vector work, with the lane utilisation of that work beside it (same PMC runs).
   value_host_to_host   the same frame through hrt_render: gamma, tile assemble and the D2H copy of the frame included.
+  without_pruning      the kernel rate of the same frame on a scene created with HRT_PRUNE=0 (no exact path pruning), and the
+                       check that the two frames are bit-identical: `value` includes an optimisation that skips provably
+                       irrelevant work, this is the rate without it.
   other_configs        kernel time of BASELINE's other configurations at their true sizes (one launch each).
   cpu_baseline  the CPU oracle (a port of the reference algorithm, reference-shaped KD-tree) timed on this host on a
                 bounded sample of the same workload, threaded three ways -- a reported baseline, not the target.
@@ -321,6 +324,22 @@ def main():
             out["value_host_to_host"] = {"value": round(W * H * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms": round(dt * 1e3, 2),
                                          "note": "hrt_render: kernel + gamma + tile assemble + D2H of the 24.9 MB frame, host call to host buffer"}
             assert np.isfinite(host_img).all()
+            # The exact path pruning of round 3 (a path ends when its throughput is exactly zero; the last segment of a
+            # path in an unlit scene is followed only if its closest sphere / square hit emits) removes work without changing a bit.
+            # Reported beside the metric so that nobody has to take that on trust: the same kernels on a scene created with the
+            # pruning switched off (HRT_PRUNE=0), the frame compared bit for bit.
+            os.environ["HRT_PRUNE"] = "0"
+            try:
+                plain = hrt.DeviceScene(desc)
+            finally:
+                del os.environ["HRT_PRUNE"]
+            plain.render(cam, 64, 64, 1, SEED)
+            plain_img, plain_st = plain.render(cam, W, H, spp, SEED, flags=hrt.FLAG_GAMMA)
+            if not np.array_equal(plain_img, host_img):
+                raise SystemExit("bench.py: the frame rendered without the pruning differs from the frame rendered with it")
+            out["without_pruning"] = {"value": round(W * H * spp / plain_st.kernel_ms / 1e3, 2), "unit": "Msamples/s (kernel time)", "kernel_ms": round(plain_st.kernel_ms, 3),
+                                      "frame": "bit-identical to the pruned frame (checked in this run)"}
+            plain.close()
             out["other_configs"] = other_configs(hrt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hrt, desc, cam)

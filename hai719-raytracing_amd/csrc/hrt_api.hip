@@ -814,6 +814,7 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         for (uint32_t i = 0; i < D.n_lights; ++i) fin3(D.lights[i].color);
         for (const float4 &c : colors) finite = finite && std::isfinite(c.x) && std::isfinite(c.y) && std::isfinite(c.z);
         d.prune_ok = finite ? 1u : 0u;
+        if (const char *e = std::getenv("HRT_PRUNE")) if (e[0] == '0') d.prune_ok = 0u;  // measurement aid: the same kernels without the pruning (bench.py reports both rates)
     }
     d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
     HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
