@@ -48,6 +48,26 @@ def many_spheres(gpu, n, n_lights, dark=False):
     return s
 
 
+def overlapping_soup(gpu, nt=200, seed=1, scale=0.5, slivers=12):
+    """A triangle soup on which the REFERENCE's builder degenerates (found by tools/fuzz_exact.py, round 3): triangles larger
+    than their spacing straddle every median cut, the tree reaches depth 100 and drops triangles below it (KDTree.cpp:101), and
+    because the cut is the median of UNCLIPPED bounds (:87-98) planes fall outside their nodes -- children stick out of their
+    parents, and a leaf is then reached only through its own box AND those ancestors' (hrt_tri_exception::group).  With
+    nt = 200, seed = 1: 117 dropped triangles, 12 797 (triangle, leaf) pairs, 27 711 box entries."""
+    rng = np.random.default_rng(1000 * nt + seed)
+    centres = rng.normal(scale=1.0, size=(nt, 1, 3))
+    v = (centres + rng.normal(scale=scale, size=(nt, 3, 3))).astype(np.float32)
+    v[:slivers, 1] = v[:slivers, 0] + (v[:slivers, 2] - v[:slivers, 0]) * np.float32(0.5) + np.float32(1e-6)   # a few (near) collinear ones
+    pos = v.reshape(-1, 3) + np.float32([0, 0.5, -4])
+    tri = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+    s = gpu.HostScene()
+    s.set_sky(False)
+    s.add_quad((-6, -3, -10), (1, 0, 0), (0, 0, 1), 12, 12, gpu.Material.make(albedo=(0.8, 0.8, 0.8)))
+    s.add_quad((-1, 4, -5), (1, 0, 0), (0, 0, 1), 2, 2, gpu.Material.make(albedo=(0, 0, 0), emissive=True, light_color=(1, 1, 1), light_intensity=8.0))
+    s.add_mesh(pos, tri, gpu.Material.make(albedo=(0.7, 0.6, 0.5)), face_colors=rng.uniform(0.1, 1, (nt, 3)).astype(np.float32))
+    return s
+
+
 def describe_difference(a, b):
     """Text for an assertion message: how many pixels differ and by how much."""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))

@@ -228,6 +228,41 @@ def test_flattened_rope_tree_equals_the_reference_tree(hrt, oracle, name):
             assert np.array_equal(ref, oracle.mesh_query(desc, m, oracle.MESH_BRUTE, rays)), (name, m)
 
 
+def test_a_degenerate_reference_tree_is_reproduced_leaf_by_leaf(hrt, oracle):
+    """scene_util.overlapping_soup: reference tree of depth 100, 117 dropped triangles, cutting planes outside their nodes.  The
+    product's walk (rope tree + exception list, on the CPU) must return the reference-shaped tree's closest triangle on every
+    ray -- which needs a reference leaf to be its own box AND the ancestor boxes that do not contain it (hrt_tri_exception::group;
+    with the leaf's box alone 1 ray in 200 found a triangle the reference never reaches)."""
+    from scene_util import overlapping_soup
+    host = overlapping_soup(hrt)
+    desc = host.flatten()
+    st = host.irregular_stats(0)
+    assert st["ref_depth"] == 100 and st["dropped"] > 50 and st["entries"] > st["pairs"]
+    lo, hi = mesh_box(desc, 0)
+    rays = _mesh_rays(np.random.default_rng(3), lo, hi, 8000)
+    ref = oracle.mesh_query(desc, 0, oracle.MESH_REF_TREE, rays)
+    rope = oracle.mesh_query(desc, 0, oracle.MESH_ROPE_TREE, rays)
+    assert ref[:, 0].sum() > 1000
+    assert np.array_equal(ref, rope), int((ref != rope).any(axis=1).sum())
+    # the leaf's own box alone is NOT the reference's rule here: drop the other boxes of every leaf and the walk finds extra hits
+    d = C.cast(desc, C.POINTER(SceneDesc)).contents
+    m = C.cast(d.meshes, C.POINTER(MeshDesc))[0]
+    exc = np.ctypeslib.as_array(C.cast(m.exceptions, C.POINTER(C.c_uint32)), shape=(m.n_exceptions, 8))
+    saved = exc.copy()
+    first_of_leaf = np.ones(len(exc), bool)
+    first_of_leaf[1:] = (exc[1:, 0] != exc[:-1, 0]) | (exc[1:, 7] != exc[:-1, 7])
+    try:
+        for i in np.nonzero(~first_of_leaf)[0]:      # make every further box of a leaf a copy of the leaf's own box: always passed with it
+            j = i
+            while not first_of_leaf[j]:
+                j -= 1
+            exc[i, 1:7] = exc[j, 1:7]
+        alone = oracle.mesh_query(desc, 0, oracle.MESH_ROPE_TREE, rays)
+    finally:
+        exc[:] = saved
+    assert (alone != ref).any(axis=1).sum() >= 2      # (4 of these 8000 rays)
+
+
 def test_irregular_triangles_are_found_and_kept_out_of_the_tree(hrt, oracle):
     """host/ref_tree.h on known meshes: flamingo_lowpoly has 64 zero-area triangles (dead: never hit, left out),
     triceratops two collinear slivers (exceptions with their reference leaf boxes), the magic staff of `raccoon` and the
