@@ -24,8 +24,9 @@ Rank 0 prints ONE JSON line.  What its evidence keys mean:
                 Infinity-Cache hits are in that count, so it is an UPPER bound on HBM bytes.  achieved = traffic / the
                 kernel's launch duration measured live here with HIP events on the launch stream; frac = achieved / 8 TB/s.  `algorithmic` keeps SURVEY 8(d)'s convention (fixed record sizes x per-sample work counters)
                 as information only: those records are served from SGPRs, LDS and L2, not from HBM.
-  valu          the bound that actually binds: SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES summed over SIMDs), i.e. the share
-                of SIMD cycles that issued vector work, with the lane utilisation of that work beside it (same PMC runs).
+  valu          the compute side: vector wave instructions per second (SQ_INSTS_VALU of the committed PMC run / the live kernel
+                time) over the MEASURED issue peak of the part (tools/micro/valu_rate.hip: 1024 SIMDs x one simple instruction
+                per 1.30 ns at this occupancy), with the lane utilisation of that work beside it (same PMC runs).
   value_host_to_host   the same frame through hrt_render: gamma, tile assemble and the D2H copy of the frame included.
   without_pruning      the kernel rate of the same frame on a scene created with HRT_PRUNE=0 (no exact path pruning), and the
                        check that the two frames are bit-identical: `value` includes an optimisation that skips provably
@@ -95,11 +96,29 @@ def committed_pmc(cfg, scene, w, h, spp):
     return j, None
 
 
-def valu_of(pmc):
-    d = pmc["derived"]
-    return {"active_simd_cycles": d["valu_active_simd_cycles"], "peak_simd_cycles": d["simd_cycles"], "frac": d["valu_busy_frac"],
-            "lane_utilisation": d["valu_lane_utilisation"], "valu_wave_insts_per_sample": d["valu_wave_insts_per_sample"],
-            "note": "SQ_ACTIVE_INST_VALU over SQ_BUSY_CYCLES x SIMDs (quad-cycles both), same rocprofv3 PMC runs as traffic"}
+def valu_of(pmc, kernel_ms):
+    """Vector-instruction issue of the trace kernel against a MEASURED peak: wave instructions of one launch (SQ_INSTS_VALU, committed
+    PMC run) / this run's live kernel time, over 1024 SIMDs x the rate of the cheapest vector instruction at this occupancy
+    (tools/micro/valu_rate.hip -> profiles/r03_valu_rate.json: 1.30 ns per instruction per SIMD).  Round 2's figure -- SQ_ACTIVE_INST_VALU
+    x 4 cycles over the SIMD cycles -- is kept as `frac_at_4_cycles_per_inst`; it is not bounded by 1 on this part (a simple fp32
+    instruction takes 2.7 cycles, not 4)."""
+    d, c = pmc["derived"], pmc["counters_per_launch"]
+    out = {"lane_utilisation": d["valu_lane_utilisation"], "valu_wave_insts_per_sample": d["valu_wave_insts_per_sample"],
+           "frac_at_4_cycles_per_inst": d["valu_busy_frac"]}
+    cal = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_valu_rate.json")
+    if os.path.exists(cal) and "SQ_INSTS_VALU" in c:
+        with open(cal) as f:
+            peak = json.load(f)["peak_wave_insts_per_ns"]
+        out["insts_per_ns"] = round(c["SQ_INSTS_VALU"] / (kernel_ms * 1e6), 1)
+        out["peak_insts_per_ns"] = peak
+        out["frac"] = round(out["insts_per_ns"] / peak, 4)
+        out["note"] = ("wave instructions per launch (SQ_INSTS_VALU, committed PMC run of the same sources) / live kernel time, over the measured issue "
+                       "rate of the cheapest vector instruction on 1024 SIMDs at 4 waves per SIMD (profiles/r03_valu_rate.json); half-rate and "
+                       "transcendental instructions cost 1.4-2.6 x that, so this is a LOWER bound on how busy the vector units are")
+    else:
+        out["frac"] = None
+        out["note"] = "no profiles/r03_valu_rate.json: the issue peak is not calibrated"
+    return out
 
 
 def cpu_baseline(hrt, desc, cam):
@@ -188,7 +207,7 @@ def other_configs(hrt):
         pmc, why = committed_pmc(tag, name, w, h, spp)
         if pmc:
             d = pmc["derived"]
-            out[tag]["valu"] = {k: valu_of(pmc)[k] for k in ("frac", "lane_utilisation", "valu_wave_insts_per_sample")}
+            out[tag]["valu"] = {k: valu_of(pmc, st.kernel_ms)[k] for k in ("frac", "lane_utilisation", "valu_wave_insts_per_sample")}
             if "fabric_bytes_per_launch" in d:
                 out[tag]["fabric_frac_of_hbm_peak"] = round(d["fabric_bytes_per_launch"] / (st.kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
             out[tag]["kernel"] = pmc["kernel"]
@@ -291,7 +310,7 @@ def main():
             "note": "achieved = L2<->fabric bytes per launch (requests by size, Infinity-Cache hits included: an upper "
                     "bound on HBM bytes) / the kernel's live HIP-event time; the kernel is VALU / latency bound, see valu",
         }
-        valu = valu_of(pmc) if pmc else None
+        valu = valu_of(pmc, avg_kernel_s * 1e3) if pmc else None
         out = {
             "metric": "Msamples/s (pixels x spp / s), Cornell+mesh 1080p@256spp",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

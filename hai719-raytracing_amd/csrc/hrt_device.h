@@ -11,7 +11,7 @@
 //             + 2 rows used only when shading: {T.xyz,0} {B.xyz,0}
 //   quad filter   DScene::qfilter, wave-uniform rows of the no-division filter (hrt_kernels.hip quad_filter):
 //               static squares (nearly) in an axis plane, by normal axis K: {sgn D, centre_I, centre_J, half_I} {half_J, bits, par, cq}
-//               all others, laid out as the SGPR pairs the packed-fp32 instructions take:
+//               all others, (R, U) and (n.y, n.z) components side by side in aligned SGPR pairs:
 //               {p0.xyz, D0} {n.y, n.z, n.x, flags | index << 8} {R.x, U.x, R.y, U.y} {R.z, U.z, |R|, |U|}
 //   materials     8 float4 rows per material, read per lane at the closest hit (rows 6, 7: geometry of its texture / normal map)
 //   meshes        DMesh records (wave-uniform)
@@ -79,8 +79,8 @@ struct DScene {
     const float4 *qfilter;     // rows of the squares' no-division filter: squares in an axis plane by normal axis x, y, z (2 rows each), then the rest (4 rows each)
     uint32_t qf_n[4];          // squares per section
     uint32_t tab_sfilter;      // row offset in `tabs` of the spheres' pair-filter rows (hrt_kernels.hip sphere_filter), 4 per PAIR of spheres
-                               // (A = 2p, B = 2p + 1; an odd last sphere is paired with itself), laid out as the register pairs the
-                               // packed-fp32 instructions take: {c.x A, c.x B, c.y A, c.y B} {c.z A, c.z B, r^2 A, r^2 B}
+                               // (A = 2p, B = 2p + 1; an odd last sphere is paired with itself), the two spheres' values side by
+                               // side: {c.x A, c.x B, c.y A, c.y B} {c.z A, c.z B, r^2 A, r^2 B}
                                // {motion.x A, B, motion.y A, B} {motion.z A, B, |r| A, |r| B}
     uint32_t sf_pairs;         // pairs; sf_psize consecutive pairs share one bit of the shadow rays' 64-bit group mask
     uint32_t sf_psize;

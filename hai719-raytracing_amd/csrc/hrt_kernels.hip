@@ -629,7 +629,8 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsu
     // load latency overlaps the ~40 VALU instructions of a quad and no row is ever copied (a rolling single-set
     // prefetch costs 16 s_mov per quad, as many issue slots as a third of the filter).
     // f0 {p0.xyz, D0}  f1 {n.y, n.z, n.x, flags | index << 8}  f2 {R.x, U.x, R.y, U.y}  f3 {R.z, U.z, |R|, |U|}: the (R, U)
-    // and (n.y, n.z) pairs sit in aligned SGPR pairs, which is how v_pk_mul/fma_f32 take them -- no scalar moves after the load.
+    // and (n.y, n.z) pairs sit in aligned SGPR pairs (a layout chosen for v_pk_mul/fma_f32; the device code is now compiled
+    // WITHOUT packed fp32 -- see the Makefile -- and the scalar instructions read the same registers).
     auto filter = [&](const float4 &f0, const float4 &f1, const float4 &f2, const float4 &f3) {
         const uint32_t flags = __float_as_uint(f1.w), i = flags >> 8;
         if (flags & HRT_QUAD_FLAG_MOVING) { cand |= (M)1 << i; return; }  // uniform branch; the exact path decides
@@ -667,8 +668,12 @@ __device__ __forceinline__ M quad_filter(const CX &cx, const Ray &ray, float tsu
 
 // FILTER over the spheres of a scene that has many (no square root, no division): which spheres can possibly give
 // Sphere::intersect an accepted hit; the exact arithmetic (sphere_t) then runs only on those, per lane, in index order.  Two
-// spheres A, B go through every instruction together: the rows hold (A, B) register pairs and the arithmetic is written on
-// two-element vectors, which gfx950 executes as v_pk_add / v_pk_mul / v_pk_fma_f32 (one issue slot for both).  For the ray
+// spheres A, B go through the arithmetic together: the rows hold (A, B) pairs and the arithmetic is written on two-element
+// vectors.  (Written for gfx950's v_pk_add / v_pk_mul / v_pk_fma_f32; on MI355X a packed instruction occupies the SIMD as long as
+// the two scalar ones it stands for and wants aligned register pairs on top -- random_spheres 1080p @ 64: 4 008 Msamples/s
+// packed, 4 252 with this function alone scalar, 4 401 with no packed fp32 anywhere -- so the Makefile compiles the device code
+// without them and each vector operation below becomes two scalar ones.  What the filter saves is the square root and the
+// division of the exact test, not issue slots through packing.)  For the ray
 // o + t d and the sphere centre c = c0 + time * motion the exact test forms  oc = o - c,  b = 2 d.oc,  cc = oc.oc - r^2,
 // delta = b^2 - 4 a cc  and has NO accepted hit when delta < 0 or when b >= 0 (then t = (-b - sqrt(delta)) / 2a <= 0 fails
 // `t >= EPSILON`).  The filter evaluates the same quantities with fused multiply-adds,
@@ -873,8 +878,8 @@ __device__ __forceinline__ Hit closest_hit(const CX &cx, const Ray &ray) {
 // reference's loop would skip it without a draw.  Bit g of the result = some sphere of group g (DScene::sf_psize
 // consecutive PAIRS of spheres) may be touched.  The test is a FILTER: its margin covers (a) its own fp32 error
 // (perpendicular-vector form, no cancellation) and (b) the error of the exact test's discriminant, which
-// cancels |oc|^2-sized terms (<= ~1e-6 |oc|^2 absolute; the margin allows 1e-5 |oc|^2).  Two spheres per instruction
-// (packed fp32, the pair rows of sphere_filter).
+// cancels |oc|^2-sized terms (<= ~1e-6 |oc|^2 absolute; the margin allows 1e-5 |oc|^2).  shadow_sphere_groups takes two
+// spheres at a time from the pair rows of sphere_filter (two-element vectors, compiled to scalar fp32 like sphere_filter).
 __device__ __forceinline__ uint64_t shadow_sphere_groups_scalar(cscene S, f3 p, f3 lpos, float reach, float time, uint32_t gsize) {
     // one sphere at a time, groups of gsize consecutive SPHERES: the kernels without the pair filter (few spheres)
     cf4 sph = (cf4)S->spheres;

@@ -447,7 +447,8 @@ def test_committed_profiles_are_of_the_committed_kernel_sources():
         summary, why = bench.committed_pmc(cfg, scene, w, h, spp)
         assert summary is not None, f"profiles/r03_{cfg}_pmc.json: {why}"
         d = summary["derived"]
-        assert d["fabric_bytes_per_launch"] > 0 and 0 < d["valu_busy_frac"] <= 1 and 0 < d["valu_lane_utilisation"] <= 1
+        # (valu_busy_frac prices an instruction at 4 cycles and is NOT bounded by 1 on this part; valu_issue_frac, against the measured peak, is)
+        assert d["fabric_bytes_per_launch"] > 0 and 0 < d["valu_issue_frac"] <= 1 and 0 < d["valu_lane_utilisation"] <= 1
         assert abs(d["fetch_factor"] - 2.0) < 0.05 and abs(d["write_factor"] - 1.0) < 0.05   # what profiles/r03_traffic_calibration.json measured for this pattern
     means = bench.committed_frame_means()
     assert len(means) == 6 and all(0 < v < 1 for v in means.values())

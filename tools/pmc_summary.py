@@ -78,6 +78,16 @@ if __name__ == "__main__":
                 avg_ms = float(r["AverageNs"]) / 1e6
                 d["kernel_trace_avg_ms"] = round(avg_ms, 3)
                 d["kernel_trace_calls"] = int(r["Calls"])
+    # Vector issue rate against a MEASURED peak.  valu_busy_frac above prices every vector instruction at 4 cycles of its SIMD (64 lanes
+    # on 16) -- on MI355X a simple fp32 instruction takes 2.7 (tools/micro/valu_rate.hip: 1.30 ns per SIMD with 4 waves per SIMD, the
+    # streaming kernel's occupancy), so that figure is NOT bounded by 1 (random_spheres: 1.17).  This one is: wave instructions per
+    # second over 1024 SIMDs x the measured rate of the cheapest instruction (half-rate and transcendental ones cost 1.4-2.6 x that).
+    cal = os.path.join(ROOT, "profiles", f"{tag}_valu_rate.json")
+    if avg_ms and "SQ_INSTS_VALU" in c and os.path.exists(cal):
+        peak = json.load(open(cal))["peak_wave_insts_per_ns"]
+        d["valu_insts_per_ns"] = round(c["SQ_INSTS_VALU"] / (avg_ms * 1e6), 1)
+        d["valu_peak_insts_per_ns"] = peak
+        d["valu_issue_frac"] = round(d["valu_insts_per_ns"] / peak, 4)
     if avg_ms and "fabric_bytes_per_launch" in d:
         d["fabric_gbps_at_trace_time"] = round(d["fabric_bytes_per_launch"] / (avg_ms / 1e3) / 1e9, 1)
         d["msamples_per_s_at_trace_time"] = round(samples / avg_ms / 1e3, 1)

@@ -6,7 +6,8 @@ instruction attributed to its source line (hipcc -gline-tables-only -S).  Runs i
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "hai719-raytracing_amd", "csrc", "hrt_api.hip")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]   # the device flags of hai719-raytracing_amd/Makefile
 KERNELS = ["hrt_wgstream_kernel", "hrt_wgstream_kernel_lights", "hrt_wgstream_kernel_sph", "hrt_wgstream_kernel_lights_sph", "hrt_trace_kernel", "hrt_trace_kernel_lights", "hrt_trace2_kernel", "hrt_trace2_kernel_lights"]
 tmp = tempfile.mkdtemp()
 asm = os.path.join(tmp, "hrt.s")

@@ -9,7 +9,7 @@ if [ "$1" = "build" ]; then
   for f in libhrt_var_*.so; do [ "$f" = libhrt_var_bound.so ] || rm -f "$f"; done
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical $flags -shared -o libhrt_var_$name.so csrc/hrt_api.hip -ldl || exit 1
+    make -s -B libhrt_var_$name.so VARIANT=libhrt_var_$name.so VARIANT_FLAGS="$flags" || exit 1   # the Makefile's two-pass build (no packed fp32 in device code)
     echo "built libhrt_var_$name.so ($flags)"
   done
 else
