@@ -816,6 +816,9 @@ static int scene_create_impl(const hrt_scene_desc *desc, hrt_scene *s) {
         d.prune_ok = finite ? 1u : 0u;
         if (const char *e = std::getenv("HRT_PRUNE")) if (e[0] == '0') d.prune_ok = 0u;  // measurement aid: the same kernels without the pruning (bench.py reports both rates)
     }
+    d.any_motion = 0u;  // (time x 0 == 0 whatever the time: with no motion anywhere a ray's time is never looked at)
+    for (uint32_t i = 0; i < D.n_materials; ++i)
+        if (!(D.materials[i].motion[0] == 0.f && D.materials[i].motion[1] == 0.f && D.materials[i].motion[2] == 0.f)) d.any_motion = 1u;
     d.skybox_image = (D.skybox_image >= 0 && D.images[D.skybox_image].w >= 1 && D.images[D.skybox_image].h >= 1) ? D.skybox_image : -1;
     HIP_TRY(hipMalloc((void **)&s->tile_counter, sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&s->stamps, 16 * sizeof(unsigned long long)));

@@ -88,6 +88,7 @@ struct DScene {
     uint32_t n_spheres, n_quads, n_meshes, n_lights, n_images;
     uint32_t n_kd_units;
     int32_t dark_sky, skybox_image;
+    uint32_t any_motion;       // some material has a motion vector != 0: only then does a ray's time matter (hrt_stream.hip recomputes it per hit visit)
     uint32_t prune_ok;         // every colour a path's throughput or radiance is multiplied by or added to is finite (materials, lights, mesh
                                // colours; texels are bytes): then throughput x value == 0 whenever the throughput is 0, which the streaming
                                // kernel's exact path pruning (hrt_stream.hip HRT_SP_PRUNE) relies on

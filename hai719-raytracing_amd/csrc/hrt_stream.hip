@@ -92,6 +92,10 @@
 #endif                     // that runs out of chunks in one stream's cycle does not idle at a barrier: it arrives (an LDS counter) and goes
                            // on with the other stream's cycle; the last wave to arrive prepares the stream's next cycle.  1 = one stream,
                            // the same code with nothing to overlap (equivalent to a barrier per cycle)
+#ifndef HRT_SP_NOG5
+#define HRT_SP_NOG5 1      // 1: hit visits do not load group 5 of the record (time, RNG keys, path number): recomputed from the number, kept in
+                           // g7.w.  1080p@64, Msamples/s Cornell+mesh / mesh_in_box / pool / random_spheres: 0 -> 3 294 / 2 831 / 1 824 / 4 419, 1 -> 3 380 / 2 951 / 1 843 / 4 541
+#endif
 #ifndef HRT_SP_THALF
 #define HRT_SP_THALF 0     // experiment: T chunks of 32 paths (half the lanes idle) -- latency- or throughput-bound?
 #endif
@@ -154,6 +158,7 @@ struct SpShared {        // what the streams of a workgroup share (8 dwords)
 static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0 && sizeof(SpUnit) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
 static_assert(HRT_SP_STREAMS == 1 || HRT_SP_STREAMS == 2, "one or two streams");
 static_assert(HRT_SP_UNITS >= 1 && HRT_SP_UNITS <= 4, "a path number carries its unit slot in its two top bits");
+static_assert(!HRT_SP_NOG5 || HRT_SP_UNIT <= 8192, "g7.w keeps 13 bits of the path's number in its unit beside the bounces left");
 static_assert(HRT_SP_QCAP >= 512, "deferring partial chunks needs a queue that can hold a whole chunk whenever fewer than 64 slots are free (6 queues x 63 < QCAP - 64)");
 
 static_assert((HRT_SP_POOL & (HRT_SP_POOL - 1)) == 0 && HRT_SP_POOL <= 65536, "slot ids are 16-bit and masked with HRT_SP_POOL - 1");
@@ -188,8 +193,8 @@ __device__ __forceinline__ SpRef<float> spf(const SpLds &L, int field, uint32_t 
 __device__ __forceinline__ SpRef<uint32_t> spu(const SpLds &L, int field, uint32_t slot) { return SpRef<uint32_t>{L.st + SP_AT(field, slot)}; }
 // A path record is read and written in its eight aligned 16-byte GROUPS (one vector memory instruction each):
 //   g0 {o.xyz, d.x}  g1 {d.y, d.z, hit t, hit kind|index}  g2 {hit a0, a1, triangle, meshes still to walk}
-//   g3 {walk ref, t_entry, cursor, best t}  g4 {best triangle, bu, bv, -}  g5 {time, RNG key k0, k1, path number}
-//   g6 {throughput.rgb, radiance.r}  g7 {radiance.g, .b, RNG position, bounces left}
+//   g3 {walk ref, t_entry, cursor, best t}  g4 {best triangle, bu, bv, -}  g5 {time, RNG key k0, k1, path number} (unused with HRT_SP_NOG5)
+//   g6 {throughput.rgb, radiance.r}  g7 {radiance.g, .b, RNG position, bounces left | path number (sp_w7)}
 // (Left to the load / store vectoriser, the per-field accesses of a hit visit became 11 loads -- three of them issued late,
 // behind the first waits -- and 7 stores of mixed widths; by group they are 6 and 5.)
 __device__ __forceinline__ uint4 sp_ld4(const SpLds &L, int g, uint32_t slot) {
@@ -212,6 +217,15 @@ __device__ __forceinline__ void sp_st4(const SpLds &L, int g, uint32_t slot, uin
 #endif
 }
 #define SP_PIN1(g) "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w)
+// g7.w: the bounces left (3 bits) and, with HRT_SP_NOG5, the path's number beside them (13 bits of path-in-unit, the unit slot on top)
+#if HRT_SP_NOG5
+__device__ __forceinline__ uint32_t sp_w7(uint32_t left, uint32_t pnum) { return left | ((pnum & 0x1FFFu) << 3) | (pnum & 0xC0000000u); }
+__device__ __forceinline__ uint32_t sp_w7_left(uint32_t w) { return w & 7u; }
+__device__ __forceinline__ uint32_t sp_w7_pnum(uint32_t w) { return ((w >> 3) & 0x1FFFu) | (w & 0xC0000000u); }
+#else
+__device__ __forceinline__ uint32_t sp_w7(uint32_t left, uint32_t) { return left; }
+__device__ __forceinline__ uint32_t sp_w7_left(uint32_t w) { return w; }
+#endif
 __device__ __forceinline__ uint4 sp_pack(float a, float b, float c, float d) { return make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)); }
 __device__ __forceinline__ void sp_unpack_ray_hit(const uint4 g0, const uint4 g1, const uint4 g2, Ray &ray, Hit &h, uint32_t &pm) {
     ray.o = mk(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z));
@@ -318,6 +332,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
     const bool has_mesh = cx.S->n_meshes != 0u;
     const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
     const bool prune = !EXACT && HRT_SP_PRUNE != 0 && cx.S->prune_ok != 0u;                // see HRT_SP_PRUNE
+    const bool moving = cx.S->any_motion != 0u;                                              // a ray's time matters
     const bool sky_is_zero = cx.S->skybox_image < 0 && cx.S->dark_sky != 0;                // Scene.h:149-152: a miss adds nothing
     float *scratch = R.sp_scratch + (size_t)blockIdx.x * ((size_t)HRT_SP_UNITS * HRT_SP_UNIT * 3u);  // one part per unit slot
     const uint32_t glog = R.sp_group_log2, G = 1u << glog, blog = R.sp_band_log2;  // tiles per unit; or ONE row band of a tile, 8 x (8 >> blog) pixels
@@ -703,9 +718,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         const float tm = rng.next();
                         ray = camera_ray<EXACT>(cam, u, v, tm);
                         pnum = n | (gs << 30);
+#if !HRT_SP_NOG5
                         sp_st4(L, 5, slot, make_uint4(__float_as_uint(tm), rng.k0, rng.k1, pnum));
+#endif
                         sp_st4(L, 6, slot, sp_pack(1.f, 1.f, 1.f, 0.f));                                  // throughput 1, radiance 0
-                        sp_st4(L, 7, slot, make_uint4(0u, 0u, rng.i, 6u));                               // MAXBOUNCES
+                        sp_st4(L, 7, slot, make_uint4(0u, 0u, rng.i, sp_w7(6u, pnum)));                  // MAXBOUNCES
                         trace = true;
                     } else {  // pixel outside a ragged image: the sample is zero, the slot stays free
                         float *o = scratch + (size_t)gs * ((size_t)HRT_SP_UNIT * 3u) + (size_t)n * 3u;
@@ -715,6 +732,28 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     }
                 } else if (act) {
                     slot = qHi[from_back ? (uint32_t)HRT_SP_QCAP - 1u - e : e] & (HRT_SP_POOL - 1u);
+#if HRT_SP_NOG5
+                    // Five groups, not six: what g5 held -- the ray's time, the keys of the path's random stream, the path's number -- never
+                    // changes after the path's first visit.  The number rides in g7.w beside the bounces left; the rest is recomputed
+                    // from it (the pixel from the unit's tile table in LDS, the sample from the unit's fold; Rng::start; the time is draw 2
+                    // of the stream, as in the G chunk): ~45 vector instructions for one vector memory instruction less per hit visit.
+                    uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
+                    asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g2), SP_PIN1(g6), SP_PIN1(g7));
+                    pnum = sp_w7_pnum(g7.w);
+                    Rng key;
+                    {
+                        const uint32_t kn = pnum & 0x3FFFFFFFu, ku = pnum >> 30;
+                        const uint32_t kq = kn & (upix - 1u), ks = U[ku].s0 + (kn >> upix_log2);
+                        const uint32_t kxy = tile_xy[ku * HRT_SP_MAXG + (kq >> 6)];
+                        const uint32_t kx = (kxy & 0xFFFFu) + (kq & 7u), ky = (kxy >> 16) + ((kq & 63u) >> 3);
+                        key.start(R.seed_lo, R.seed_hi, ky * R.w + kx, R.s0 + ks);
+                        key.i = 2u;
+                    }
+                    Hit h;
+                    uint32_t pm_unused;
+                    sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
+                    ray.time = moving ? key.next() : 0.f;  // (time x 0 == 0: without motion the time is never looked at)
+#else
                     uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g5 = sp_ld4(L, 5, slot),
                           g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
 #if HRT_SP_GLOBAL
@@ -724,10 +763,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     uint32_t pm_unused;
                     sp_unpack_ray_hit(g0, g1, g2, ray, h, pm_unused);
                     ray.time = __uint_as_float(g5.x);
+                    pnum = g5.w;
+#endif
                     f3 thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
                     rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
-                    int remaining = (int)g7.w;
-                    pnum = g5.w;
+                    int remaining = (int)sp_w7_left(g7.w);
 #ifdef HRT_SP_SEG
                     asm volatile("" : "+v"(remaining), "+v"(ray.o.x), "+v"(thr.x), "+v"(rad.x));
 #endif
@@ -737,7 +777,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         ended = true;
                     } else {
                         Rng rng;
+#if HRT_SP_NOG5
+                        rng.k0 = key.k0; rng.k1 = key.k1; rng.i = g7.z;
+#else
                         rng.k0 = g5.y; rng.k1 = g5.z; rng.i = g7.z;
+#endif
                         const Surface sf = shade(cx, ray, h);
                         SEG(1);  // shade: material rows, texel, normal map
                         f3 direct = mk(0.f, 0.f, 0.f);
@@ -752,7 +796,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         if ((HRT_SP_PRUNE & 1) && prune && thr.x == 0.f && thr.y == 0.f && thr.z == 0.f) ended = true;  // nothing can reach the sample any more
                         if (!ended) {
                             sp_st4(L, 6, slot, sp_pack(thr.x, thr.y, thr.z, rad.x));
-                            sp_st4(L, 7, slot, make_uint4(__float_as_uint(rad.y), __float_as_uint(rad.z), rng.i, (uint32_t)remaining));
+                            sp_st4(L, 7, slot, make_uint4(__float_as_uint(rad.y), __float_as_uint(rad.z), rng.i, sp_w7((uint32_t)remaining, pnum)));
                             trace = true;
                             last_seg = (HRT_SP_PRUNE & 2) && !LIGHTS && prune && remaining == 1;
                         }
@@ -780,7 +824,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                         const uint4 g6 = sp_ld4(L, 6, slot), g7 = sp_ld4(L, 7, slot);
                         thr = mk(__uint_as_float(g6.x), __uint_as_float(g6.y), __uint_as_float(g6.z));
                         rad = mk(__uint_as_float(g6.w), __uint_as_float(g7.x), __uint_as_float(g7.y));
-                        remaining = (int)g7.w;
+                        remaining = (int)sp_w7_left(g7.w);
                     }
                     rad = rad + thr * sky(cx, ray.d, remaining);
                     trace = false; ended = true; last_seg = false;
