@@ -96,6 +96,11 @@
 #define HRT_SP_NOG5 1      // 1: hit visits do not load group 5 of the record (time, RNG keys, path number): recomputed from the number, kept in
                            // g7.w.  1080p@64, Msamples/s Cornell+mesh / mesh_in_box / pool / random_spheres: 0 -> 3 294 / 2 831 / 1 824 / 4 419, 1 -> 3 380 / 2 951 / 1 843 / 4 541
 #endif
+#ifndef HRT_SP_PM4
+#define HRT_SP_PM4 1       // 1: the meshes still to walk and the walk ref travel in g4 and a T visit loads four groups (not g2); the sender's one store
+                           // of g4 replaces the invariant "walk ref NIL outside T" and its two dword stores.  1080p@64, Msamples/s Cornell+mesh /
+                           // mesh_in_box / pool: 0 -> 3 373 / 2 945 / 1 843, 1 -> 3 437 / 2 970 / 1 855
+#endif
 #ifndef HRT_SP_THALF
 #define HRT_SP_THALF 0     // experiment: T chunks of 32 paths (half the lanes idle) -- latency- or throughput-bound?
 #endif
@@ -193,7 +198,8 @@ __device__ __forceinline__ SpRef<float> spf(const SpLds &L, int field, uint32_t 
 __device__ __forceinline__ SpRef<uint32_t> spu(const SpLds &L, int field, uint32_t slot) { return SpRef<uint32_t>{L.st + SP_AT(field, slot)}; }
 // A path record is read and written in its eight aligned 16-byte GROUPS (one vector memory instruction each):
 //   g0 {o.xyz, d.x}  g1 {d.y, d.z, hit t, hit kind|index}  g2 {hit a0, a1, triangle, meshes still to walk}
-//   g3 {walk ref, t_entry, cursor, best t}  g4 {best triangle, bu, bv, -}  g5 {time, RNG key k0, k1, path number} (unused with HRT_SP_NOG5)
+//   g3 {best triangle, t_entry, cursor, best t}  g4 {walk ref, bu, bv, meshes still to walk} (HRT_SP_PM4; else g3.x walk ref, g4.x triangle, g2.w meshes)
+//   g5 {time, RNG key k0, k1, path number} (unused with HRT_SP_NOG5)
 //   g6 {throughput.rgb, radiance.r}  g7 {radiance.g, .b, RNG position, bounces left | path number (sp_w7)}
 // (Left to the load / store vectoriser, the per-field accesses of a hit visit became 11 loads -- three of them issued late,
 // behind the first waits -- and 7 stores of mixed widths; by group they are 6 and 5.)
@@ -640,6 +646,19 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 SEG_START(HRT_SP_SEG_KIND == 2);
                 if (act) {
                     slot = qTi[e] & (HRT_SP_POOL - 1u);
+#if HRT_SP_PM4
+                    // Four groups: a T visit needs the ray, the distance and kind of the best hit so far, the state of its walk and the
+                    // meshes still to walk -- which the chunk that sent the path here wrote into the free dword of g4 -- but not the
+                    // hit's a0 / a1 / triangle (g2): those it only ever REPLACES, when a mesh gives a closer hit.
+                    uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g3 = sp_ld4(L, 3, slot), g4 = sp_ld4(L, 4, slot);
+                    asm volatile("" : SP_PIN1(g0), SP_PIN1(g1), SP_PIN1(g3), SP_PIN1(g4));
+                    {
+                        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                        sp_unpack_ray_hit(g0, g1, z, ray, h, pm);
+                    }
+                    pm = g4.w;
+                    pm_before = __float_as_uint(h.t);  // (here: the best distance on entry)
+#else
                     uint4 g0 = sp_ld4(L, 0, slot), g1 = sp_ld4(L, 1, slot), g2 = sp_ld4(L, 2, slot), g3 = sp_ld4(L, 3, slot),
                           g4 = sp_ld4(L, 4, slot);
 #if HRT_SP_GLOBAL
@@ -647,9 +666,15 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #endif
                     sp_unpack_ray_hit(g0, g1, g2, ray, h, pm);  // (the mesh walk does not read ray.time)
                     pm_before = pm;
+#endif
+#if HRT_SP_PM4   // g3 {best triangle, t_entry, cursor, best t}  g4 {walk ref, bu, bv, meshes to walk}: the sender's ONE store of g4 also says "no walk in progress"
+                    w.ref = g4.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
+                    w.best_tri = g3.x; w.bu = __uint_as_float(g4.y); w.bv = __uint_as_float(g4.z);
+#else
                     w.ref = g3.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
-                    ref_in = w.ref;
                     w.best_tri = g4.x; w.bu = __uint_as_float(g4.y); w.bv = __uint_as_float(g4.z);
+#endif
+                    ref_in = w.ref;
                 }
 #ifdef HRT_SP_SEG
                 asm volatile("" : "+v"(ray.o.x), "+v"(w.t_entry), "+v"(h.t));
@@ -665,16 +690,28 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 SEG(1);  // T: walk
                 if (act) {
                     const uint32_t pm_in = pm_before;
+#if HRT_SP_PM4
+                    if (__float_as_uint(h.t) != pm_in) {  // a mesh gave a closer hit (g1 also carries d.y, d.z: rewritten as read)
+#else
                     if (pm != pm_in) {  // a mesh was finished: the best hit may have changed (g1 also carries d.y, d.z: rewritten as read)
+#endif
                         sp_st4(L, 1, slot, make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(h.t), (h.kind << 28) | h.index));
                         sp_st4(L, 2, slot, make_uint4(__float_as_uint(h.a0), __float_as_uint(h.a1), h.tri, pm));
                     }
+#if HRT_SP_PM4
+                    if (!walked) {  // the state of the walk in progress, and the meshes still to walk
+                        sp_st4(L, 3, slot, make_uint4(w.best_tri, __float_as_uint(w.t_entry), w.kk, __float_as_uint(w.best_t)));
+                        sp_st4(L, 4, slot, make_uint4(w.ref, __float_as_uint(w.bu), __float_as_uint(w.bv), pm));
+                    }
+                    (void)ref_in;
+#else
                     if (!walked) {  // the state of the walk in progress
                         sp_st4(L, 3, slot, make_uint4(w.ref, __float_as_uint(w.t_entry), w.kk, __float_as_uint(w.best_t)));
                         sp_st4(L, 4, slot, make_uint4(w.best_tri, __float_as_uint(w.bu), __float_as_uint(w.bv), 0u));
                     } else if (ref_in != HRT_KD_NIL) {
                         spu(L, SP_WREF, slot) = HRT_KD_NIL;  // invariant: SP_WREF is NIL whenever the path is not in a T queue
                     }
+#endif
                     kind = h.kind;
                 }
 #if HRT_SP_TPRIO
@@ -849,7 +886,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 }
                 if (trace) {
                     sp_store_ray_hit(L, slot, ray, hn, pmn);
+#if HRT_SP_PM4
+                    if (pmn != 0u) sp_st4(L, 4, slot, make_uint4(HRT_KD_NIL, 0u, 0u, pmn));  // no walk in progress; the meshes to walk, where the T visit looks for them
+#else
                     if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
+#endif
                     to_mesh = pmn != 0u;
                     kind = hn.kind;
                 }
