@@ -101,6 +101,10 @@
                            // of g4 replaces the invariant "walk ref NIL outside T" and its two dword stores.  1080p@64, Msamples/s Cornell+mesh /
                            // mesh_in_box / pool: 0 -> 3 373 / 2 945 / 1 843, 1 -> 3 437 / 2 970 / 1 855
 #endif
+#ifndef HRT_SP_PMQ
+#define HRT_SP_PMQ 1       // 1 (needs HRT_SP_PM4): in scenes of <= 4 meshes the meshes to walk ride in the T-queue entry beside the slot id; the sender stores
+                           // no g4.  1080p@64, Msamples/s Cornell+mesh / mesh_in_box / pool: 0 -> 3 443 / 2 974 / 1 875, 1 -> 3 475 / 3 021 / 1 890
+#endif
 #ifndef HRT_SP_THALF
 #define HRT_SP_THALF 0     // experiment: T chunks of 32 paths (half the lanes idle) -- latency- or throughput-bound?
 #endif
@@ -163,6 +167,7 @@ struct SpShared {        // what the streams of a workgroup share (8 dwords)
 static_assert(sizeof(SpCtl) % 16 == 0 && sizeof(SpShared) % 16 == 0 && sizeof(SpUnit) % 16 == 0, "the LDS regions behind the control blocks must stay 16-byte aligned");
 static_assert(HRT_SP_STREAMS == 1 || HRT_SP_STREAMS == 2, "one or two streams");
 static_assert(HRT_SP_UNITS >= 1 && HRT_SP_UNITS <= 4, "a path number carries its unit slot in its two top bits");
+static_assert(!HRT_SP_PMQ || (HRT_SP_PM4 && HRT_SP_POOL <= 4096), "a T-queue entry is 12 bits of slot id + 4 bits of meshes");
 static_assert(!HRT_SP_NOG5 || HRT_SP_UNIT <= 8192, "g7.w keeps 13 bits of the path's number in its unit beside the bounces left");
 static_assert(HRT_SP_QCAP >= 512, "deferring partial chunks needs a queue that can hold a whole chunk whenever fewer than 64 slots are free (6 queues x 63 < QCAP - 64)");
 
@@ -337,6 +342,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
         q_all[(i / HRT_SP_QCAP) * (HRT_SP_NQ * HRT_SP_QCAP) + (2 * 3 + 0) * HRT_SP_QCAP + (i % HRT_SP_QCAP)] = (uint16_t)i;
     const bool has_mesh = cx.S->n_meshes != 0u;
     const bool multi_mesh = cx.S->n_meshes > 1u;  // T chunks then mix lanes that wait for different meshes
+#if HRT_SP_PMQ
+    const bool pm_in_entry = cx.S->n_meshes <= 4u;  // the meshes to walk fit beside the slot id in a T-queue entry (12 + 4 bits)
+#endif
     const bool prune = !EXACT && HRT_SP_PRUNE != 0 && cx.S->prune_ok != 0u;                // see HRT_SP_PRUNE
     const bool moving = cx.S->any_motion != 0u;                                              // a ray's time matters
     const bool sky_is_zero = cx.S->skybox_image < 0 && cx.S->dark_sky != 0;                // Scene.h:149-152: a miss adds nothing
@@ -645,7 +653,12 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 w.ref = HRT_KD_NIL; w.t_entry = 0.f; w.kk = 0xFFFFu; w.best_t = HRT_FLT_MAX; w.best_tri = 0; w.bu = 0.f; w.bv = 0.f;
                 SEG_START(HRT_SP_SEG_KIND == 2);
                 if (act) {
+#if HRT_SP_PMQ
+                    const uint32_t entry = qTi[e];
+                    slot = entry & (HRT_SP_POOL - 1u);
+#else
                     slot = qTi[e] & (HRT_SP_POOL - 1u);
+#endif
 #if HRT_SP_PM4
                     // Four groups: a T visit needs the ray, the distance and kind of the best hit so far, the state of its walk and the
                     // meshes still to walk -- which the chunk that sent the path here wrote into the free dword of g4 -- but not the
@@ -673,6 +686,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
 #else
                     w.ref = g3.x; w.t_entry = __uint_as_float(g3.y); w.kk = g3.z; w.best_t = __uint_as_float(g3.w);
                     w.best_tri = g4.x; w.bu = __uint_as_float(g4.y); w.bv = __uint_as_float(g4.z);
+#endif
+#if HRT_SP_PMQ
+                    // A path that comes from a hit / new-path chunk carries its meshes in the queue entry (the sender then wrote nothing into g4):
+                    // no walk in progress.  One that comes back from a T visit has 0 there and its state in g3 / g4.
+                    if (pm_in_entry && (entry >> 12) != 0u) { w.ref = HRT_KD_NIL; pm = entry >> 12; }
 #endif
                     ref_in = w.ref;
                 }
@@ -718,7 +736,7 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 __builtin_amdgcn_s_setprio(0);
 #endif
                 // unfinished: joins the next cycle's T chunks; finished: the closest-hit queue of its kind
-                sp_push_all(L, C, parity ^ 1u, !act ? SP_TO_NONE : (walked ? 1u + kind : 0u), slot);
+                sp_push_all(L, C, parity ^ 1u, !act ? SP_TO_NONE : (walked ? 1u + kind : 0u), slot);  // (back to T: a bare slot id, the state is in g3 / g4)
                 SEG(2);  // T: stores + appends
 #ifdef HRT_SP_SEG
                 if (seg_on) { seg[7] += 1; seg[6] += (unsigned long long)__popcll(__ballot(act)); seg[5] += (unsigned long long)__popcll(__ballot(act && walked)); }
@@ -887,6 +905,9 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                 if (trace) {
                     sp_store_ray_hit(L, slot, ray, hn, pmn);
 #if HRT_SP_PM4
+#if HRT_SP_PMQ
+                    if (!pm_in_entry)
+#endif
                     if (pmn != 0u) sp_st4(L, 4, slot, make_uint4(HRT_KD_NIL, 0u, 0u, pmn));  // no walk in progress; the meshes to walk, where the T visit looks for them
 #else
                     if (is_gen) spu(L, SP_WREF, slot) = HRT_KD_NIL;  // a fresh slot: no walk in progress (T keeps it so afterwards)
@@ -894,7 +915,11 @@ __device__ __forceinline__ void stream_body(const DRender &R) {
                     to_mesh = pmn != 0u;
                     kind = hn.kind;
                 }
+#if HRT_SP_PMQ
+                sp_push_all(L, C, parity ^ 1u, trace ? (to_mesh ? 0u : 1u + kind) : (freed ? 5u : SP_TO_NONE), (trace && to_mesh && pm_in_entry) ? (slot | (pmn << 12)) : slot);
+#else
                 sp_push_all(L, C, parity ^ 1u, trace ? (to_mesh ? 0u : 1u + kind) : (freed ? 5u : SP_TO_NONE), slot);
+#endif
 #pragma unroll
                 for (uint32_t k = 0; k < HRT_SP_UNITS; ++k) fin[k] += (uint32_t)__popcll(__ballot(freed && fin_unit == k));
                 SEG(6);  // record stores + queue appends
