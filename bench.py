@@ -308,8 +308,16 @@ def main():
                             "gbps": round(bps * launch_samples / avg_kernel_s / 1e9, 1),
                             "note": "SURVEY 8(d) convention (record sizes x work counters): served from SGPRs / LDS / L2, not a bandwidth"},
             "note": "achieved = L2<->fabric bytes per launch (requests by size, Infinity-Cache hits included: an upper "
-                    "bound on HBM bytes) / the kernel's live HIP-event time; the kernel is VALU / latency bound, see valu",
+                    "bound on HBM bytes) / the kernel's live HIP-event time; see attainable and valu",
         }
+        coop = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_record_coop.json")
+        if os.path.exists(coop):  # what a kernel that does NOTHING but hit visits of this record pool reaches on the same counters
+            with open(coop) as f:
+                cj = json.load(f)["counters"]
+            roofline["attainable"] = {"gbps": round(cj["gather"]["fabric_tbps"] * 1e3, 1), "gbps_cooperative_access": round(cj["coop"]["fabric_tbps"] * 1e3, 1),
+                                      "frac_of_attainable": None if achieved is None else round(achieved / (cj["gather"]["fabric_tbps"] * 1e3), 3),
+                                      "note": "tools/micro/record_coop.hip under the same request counters (profiles/r03_record_coop.json): 5 group loads + 5 group stores per "
+                                              "lane on random 128-byte records of a 128 MiB pool, nothing else -- the fabric rate this access pattern reaches on this part"}
         valu = valu_of(pmc, avg_kernel_s * 1e3) if pmc else None
         out = {
             "metric": "Msamples/s (pixels x spp / s), Cornell+mesh 1080p@256spp",
